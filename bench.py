@@ -1,0 +1,308 @@
+#!/usr/bin/env python
+"""bench.py -- Mrays/s forward+backward of the HIP Voronoi tracer on synthetic foams.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
+For N>1 it is launched under ``python -m torch.distributed.run`` with one rank per GPU.
+
+Workload (BASELINE.json metric: "Mrays/s fwd+bwd @1080p, 2M-pt foam"): the north-star point of
+SURVEY.md 8(d) -- N=2,000,000 seeded uniform points (kd-ordered, Qhull CSR, empty shell beyond
+r=0.8), SH degree 2 (A=28), fp32 attributes, one 1080x1920 pinhole frame per GPU, default
+trace settings (weight_threshold 1e-3, max_intersections 1024), upstream gradient ~ N(0,1).
+One "step" = trace_forward + trace_backward of that frame through the radfoam boundary (the
+per-step foam packing -- what the reference redoes in both calls -- runs once, in forward, and
+is inside the timed region), plus, for N>1, the SUM all-reduce of the flat gradient buffer
+over RCCL.  Rays shard by frame rows: rank r owns rows [r*H,(r+1)*H) of an [N*H, W] ray grid
+(one camera per rank, orbiting the foam), foam replicated => weak scaling.
+
+All inputs are resident in HBM before the timed region.  value = total rays / max-over-ranks
+wall time.  roofline: the dominant kernel (backward), algorithmic bytes per SURVEY.md 8(d)
+from exact walk counters, duration from HIP events recorded around that launch on the launch
+stream inside the timed region.  cpu_baseline: the C oracle (a port -- the reference has no
+CPU tracer) on a bounded sample of the same rays, all host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=2_000_000)
+    ap.add_argument("--sh-degree", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--backward-mode", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
+    ap.add_argument("--forward-only", action="store_true")
+    return ap.parse_args()
+
+
+def orbit_camera(width, height, rank):
+    """Rank r looks at the foam centre from distance 3, rotated r*45deg about +y (rank 0 is the
+    SURVEY 8(d) camera at (0,0,-3) looking +z)."""
+    from radfoam_amd import foam
+
+    cam = foam.default_camera(width, height)
+    th = rank * math.pi / 4.0
+    c, s = math.cos(th), math.sin(th)
+    pos = np.array([-3.0 * s, 0.0, -3.0 * c], dtype=np.float32)
+    fwd = np.array([s, 0.0, c], dtype=np.float32)
+    right = np.array([c, 0.0, -s], dtype=np.float32)
+    cam["position"], cam["forward"], cam["right"] = pos, fwd, right
+    return cam
+
+
+def algorithmic_bytes(stats, num_rays, attr_dim, c=4, nq=0):
+    """logical bytes, no cache reuse credited, no padding, no zero atomics."""
+    cells, faces, hops = stats["cells_scanned"], stats["faces_scanned"], stats["hops"]
+    seg, lit = stats["segments"], stats["segments_lit"]
+    attr_read = c * (seg + (attr_dim - 1) * lit)          # density always, SH row only when lit
+    walk = 8 * cells + 8 * faces + (4 + 12) * hops
+    fwd = num_rays * (24 + 4 + 4 * c + 4 + 12 * nq) + walk + attr_read
+    bwd = num_rays * (24 + 4 + 8 * c + 12 * nq) + walk + attr_read + attr_read + 12 * seg
+    return fwd, bwd
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the tracer has no CPU path")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import radfoam
+    from radfoam_amd import foam
+
+    # ---- inputs (resident before timing) -------------------------------------------------------
+    t_setup = time.time()
+    cache = foam.default_cache_dir()
+    if world > 1:
+        if rank == 0:
+            fm = foam.make_synthetic_foam(args.points, args.sh_degree, args.seed, cache_dir=cache)
+        dist.barrier()
+        if rank != 0:
+            fm = foam.make_synthetic_foam(args.points, args.sh_degree, args.seed, cache_dir=cache)
+    else:
+        fm = foam.make_synthetic_foam(args.points, args.sh_degree, args.seed, cache_dir=cache)
+    cam = orbit_camera(args.width, args.height, rank)
+    rays_np = foam.camera_rays(cam)
+    start_idx = foam.nearest_point(fm["points"], cam["position"])
+    setup_s = time.time() - t_setup
+
+    points = torch.from_numpy(fm["points"]).to(dev)
+    attributes = torch.from_numpy(fm["attributes"]).to(dev)
+    adjacency = torch.from_numpy(fm["point_adjacency"]).to(dev)
+    offsets = torch.from_numpy(fm["point_adjacency_offsets"]).to(dev)
+    rays = torch.from_numpy(rays_np).to(dev)
+    start = torch.full(rays.shape[:-1], start_idx, dtype=torch.int64).to(torch.uint32).to(dev)
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    grad_rgba = torch.randn(rays.shape[:-1] + (4,), generator=gen).to(dev)
+    num_rays = rays.numel() // 6
+
+    pipe = radfoam.create_pipeline(args.sh_degree, torch.float32)
+    pipe.backward_mode = args.backward_mode
+    A = pipe.attribute_dim()
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    fwd_ev, bwd_ev = [], []
+
+    def step(record):
+        # points are "updated by the optimizer" every step: the packed foam is rebuilt once per step
+        pipe._cache.clear()
+        if record:
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+        out = pipe.trace_forward(points, attributes, adjacency, offsets, rays, start)
+        if record:
+            e1.record()
+        if not args.forward_only:
+            res = pipe.trace_backward(points, attributes, adjacency, offsets, rays, start, out["rgba"], grad_rgba)
+            if record:
+                e2.record()
+            if world > 1:
+                # [points_grad | attr_grad] live in one flat fp32 buffer: a single collective
+                dist.all_reduce(res["flat_grad"])
+        if record:
+            fwd_ev.append((e0, e1))
+            if not args.forward_only:
+                bwd_ev.append((e1, e2))
+        return out
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_ev]))
+    bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in bwd_ev])) if bwd_ev else 0.0
+
+    # ---- exact walk counters -> algorithmic bytes (untimed) -------------------------------------
+    stats = pipe.walk_statistics(points, attributes, adjacency, offsets, rays, start)
+    bytes_fwd, bytes_bwd = algorithmic_bytes(stats, num_rays, A)
+    # forward event span includes the per-step foam packing; report the walk kernel's own share
+    e0, e1, e2 = ev(), ev(), ev()
+    pipe._cache.clear()
+    e0.record()
+    pipe.trace_forward(points, attributes, adjacency, offsets, rays, start)
+    e1.record()
+    pipe.trace_forward(points, attributes, adjacency, offsets, rays, start)  # packed foam cached
+    e2.record()
+    torch.cuda.synchronize()
+    fwd_with_pack_ms, fwd_cached_ms = e0.elapsed_time(e1), e1.elapsed_time(e2)
+
+    total_rays = num_rays * world
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rays / (elapsed / args.steps) / 1e6
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    dom_is_bwd = (not args.forward_only) and bwd_ms >= fwd_ms
+    dom_bytes, dom_ms = (bytes_bwd, bwd_ms) if dom_is_bwd else (bytes_fwd, fwd_ms)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    result = {
+        "metric": "Mrays/s fwd+bwd @1080p, 2M-pt foam; achieved HBM GB/s vs peak",
+        "value": round(value, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"north-star: synthetic {args.points}-point foam (seed {args.seed}), SH degree "
+                        f"{args.sh_degree} (A={A}), fp32 attrs, {args.height}x{args.width} pinhole frame per GPU, "
+                        f"{'forward only' if args.forward_only else 'forward+backward'}"
+                        + (", SUM all-reduce of [points_grad|attr_grad]" if world > 1 else ""),
+            "num_points": args.points, "sh_degree": args.sh_degree, "rays_per_gpu": num_rays,
+            "weight_threshold": 1e-3, "max_intersections": 1024,
+            "parallelism": f"rows of the ray grid sharded over {world} GPU(s), foam replicated",
+            "backward_mode": args.backward_mode,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "backward_kernel" if dom_is_bwd else "forward_kernel",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": int(dom_bytes),
+            "avg_launch_ms": round(dom_ms, 4),
+        },
+        "detail": {
+            "forward_ms": round(fwd_ms, 4), "backward_ms": round(bwd_ms, 4),
+            "forward_ms_packed_foam_cached": round(fwd_cached_ms, 4),
+            "foam_pack_ms": round(max(fwd_with_pack_ms - fwd_cached_ms, 0.0), 4),
+            "algorithmic_bytes_fwd": int(bytes_fwd), "algorithmic_bytes_bwd": int(bytes_bwd),
+            "fwd_GBps": round(bytes_fwd / (fwd_ms * 1e-3) / 1e9, 1),
+            "walk": stats,
+            "mean_cells_per_ray": round(stats["cells_scanned"] / num_rays, 2),
+            "mean_faces_per_cell": round(stats["faces_scanned"] / max(stats["cells_scanned"], 1), 2),
+            "setup_seconds": round(setup_s, 1),
+        },
+    }
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same rays --------------------------
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, fm, rays_np, start_idx, out, grad_rgba)
+        except Exception as exc:  # the baseline must never take the bench line down
+            result["cpu_baseline"] = {"error": repr(exc)}
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, fm, rays_np, start_idx, gpu_out, grad_rgba):
+    """Oracle (kind 'port') forward+backward on a strided sample of the frame, all host cores."""
+    from oracle import oracle as O
+
+    cores = os.cpu_count() or 1
+    h, w = rays_np.shape[:2]
+    # pilot on a coarse grid to size the sample for ~cpu_seconds
+    diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"], pad=32)
+    foam_args = (args.sh_degree, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    g_np = grad_rgba.cpu().numpy()
+
+    def run(sy, sx):
+        r = np.ascontiguousarray(rays_np[::sy, ::sx])
+        g = np.ascontiguousarray(g_np[::sy, ::sx])
+        t0 = time.perf_counter()
+        f = O.trace_forward(*foam_args, r, np.uint32(start_idx), diff=diff)
+        t1 = time.perf_counter()
+        if not args.forward_only:
+            O.trace_backward(*foam_args, r, np.uint32(start_idx), f["rgba"], g, diff=diff)
+        t2 = time.perf_counter()
+        return r.shape[0] * r.shape[1], t1 - t0, t2 - t1, f
+
+    n_pilot, tf, tb, _ = run(24, 24)
+    rate = n_pilot / max(tf + tb, 1e-6)
+    want = max(n_pilot, int(rate * args.cpu_seconds))
+    stride = max(1, int(math.sqrt(h * w / want)))
+    n, tf, tb, f = run(stride, stride)
+    # sanity: the sampled CPU rays agree with the GPU frame bit-for-bit
+    same = bool(np.array_equal(f["rgba"].view(np.uint32),
+                               gpu_out["rgba"].cpu().numpy()[::stride, ::stride].view(np.uint32)))
+    return {
+        "value": round(n / (tf + tb) / 1e6, 5),
+        "unit": "Mrays/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"every {stride}th row and column of the same frame ({n} rays), oracle/rf_oracle.c with OpenMP "
+                  f"on {O.lib().rfo_max_threads()} threads; forward {tf:.2f}s + backward {tb:.2f}s; fp16 face table "
+                  f"prebuilt (excluded, as on the GPU side it is ~1% of a step)",
+        "matches_gpu_bitwise": same,
+    }
+
+
+if __name__ == "__main__":
+    main()

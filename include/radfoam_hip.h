@@ -1,0 +1,148 @@
+/*
+ * radfoam_hip.h -- C-ABI of the MI355X-native Voronoi ray tracer (libradfoam_hip.so).
+ *
+ * This is the drop-in boundary for the reference's native tracing library: every entry
+ * point replaces one method of radfoam::Pipeline / one free function of
+ * /root/reference/src/tracing/pipeline.h (cited per function).  Plain pointers and sizes
+ * only: all pointers are DEVICE pointers (tensor.data_ptr()) unless marked HOST, `stream`
+ * is a hipStream_t passed as void* (NULL = default stream).  No torch types.
+ *
+ * Where the reference selects a template instance <attr_scalar, sh_degree> through
+ * create_pipeline() (pipeline.cu:776-805), these functions take (sh_degree, attr_type).
+ *
+ * Every function returns RF_OK (0) or a negative rf_status and records a message that
+ * rf_last_error() returns (thread-local).  Launch errors (hipGetLastError) are reported
+ * the same way, like cuda_check() after launch_kernel_1d (src/utils/common_kernels.cuh:40).
+ * Nothing synchronises the device.
+ */
+#ifndef RADFOAM_HIP_H
+#define RADFOAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rf_status {
+    RF_OK = 0,
+    RF_ERR_INVALID_ARGUMENT = -1, /* unsupported sh_degree / attr_type / null pointer / bad size */
+    RF_ERR_WORKSPACE = -2,        /* workspace missing or too small                               */
+    RF_ERR_LAUNCH = -3            /* HIP runtime error while launching                            */
+} rf_status;
+
+/* attribute scalar type: radfoam::ScalarType subset used by create_pipeline (typing.h:23-30) */
+typedef enum rf_attr_type { RF_ATTR_FLOAT32 = 0, RF_ATTR_FLOAT16 = 1 } rf_attr_type;
+
+/* radfoam::TraceSettings, src/tracing/pipeline.h:10-13 (defaults :15-20: 1e-3, 1024) */
+typedef struct rf_trace_settings {
+    float weight_threshold;
+    uint32_t max_intersections;
+} rf_trace_settings;
+
+/* radfoam::Camera by value, src/tracing/camera.h:17-26 (HOST struct) */
+typedef struct rf_camera {
+    float position[3];
+    float forward[3];
+    float right[3];
+    float up[3];
+    float fov;       /* vertical, radians */
+    uint32_t width;
+    uint32_t height;
+    uint32_t model;  /* 0 = Pinhole, 1 = Fisheye (camera.h:12-15) */
+} rf_camera;
+
+/* Launch options that have no counterpart in the reference (all optional; zero-init = defaults). */
+typedef struct rf_launch_opts {
+    void *workspace;          /* device scratch, >= rf_workspace_bytes(); holds the packed foam      */
+    size_t workspace_bytes;
+    uint32_t foam_prepared;   /* 1: workspace already holds rf_prepare_foam() output for these inputs */
+    uint32_t image_width;     /* rays form a row-major [image_height, image_width] grid: lets a wave  */
+    uint32_t image_height;    /*   own an 8x8 pixel tile.  0,0 = treat rays as a flat list            */
+    uint32_t backward_mode;   /* rf_trace_backward only: 0 = auto, 1 = per-lane atomics, 2 = wave     */
+                              /*   pre-reduced atomics                                                */
+    uint64_t *stats;          /* optional device uint64[8]: walk counters for the roofline figure     */
+                              /*   [0] cells scanned [1] faces scanned [2] hops [3] segments          */
+                              /*   [4] lit segments; accumulated with atomics, caller zeroes          */
+} rf_launch_opts;
+
+/* Last error message of the calling thread ("" if none). */
+const char *rf_last_error(void);
+
+/* Pipeline::attribute_dim(), pipeline.cu:768-770: 1 + 3*(d+1)^2, or 0 if d is unsupported. */
+uint32_t rf_attribute_dim(int sh_degree);
+
+/* Bytes of device scratch the tracer needs for a foam of this size (packed cell records,
+ * fp16 face-offset table with the reference's +32 pad, repacked SH rows when the attribute
+ * row is not 16-byte aligned).  Replaces the per-call CUDAArray<Vec4h>(E+32) of
+ * pipeline.cu:613,667. */
+size_t rf_workspace_bytes(uint32_t num_points, uint32_t point_adjacency_size, int sh_degree,
+                          int attr_type);
+
+/* prefetch_adjacent_diff(), src/tracing/pipeline.h:46-53 / pipeline.cu:546-586:
+ * adjacent_diff[e] = half4(points[adj[e]] - points[owner(e)], 0), RNE.  adjacent_diff holds
+ * point_adjacency_size entries of 8 bytes. */
+int rf_build_adjacent_diff(const float *points, uint32_t num_points,
+                           uint32_t point_adjacency_size, const uint32_t *point_adjacency,
+                           const uint32_t *point_adjacency_offsets, void *adjacent_diff,
+                           void *stream);
+
+/* Packs the foam into `workspace` for the walk kernels: cell records {x,y,z,density,begin,end},
+ * the fp16 face-offset table (same values as rf_build_adjacent_diff) and aligned SH rows.
+ * The reference does the equivalent (prefetch_adjacent_diff) inside every trace_forward /
+ * trace_backward call (pipeline.cu:613-620,667-674); here the result may be reused while
+ * points/attributes/adjacency are unchanged (opts->foam_prepared). */
+int rf_prepare_foam(int sh_degree, int attr_type, uint32_t num_points, const float *points,
+                    const void *attributes, uint32_t point_adjacency_size,
+                    const uint32_t *point_adjacency, const uint32_t *point_adjacency_offsets,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Pipeline::trace_forward, src/tracing/pipeline.h:62-78 (kernel: pipeline.cu:14-130).
+ * rays: [num_rays][6] (origin, direction; direction is normalised in the kernel).
+ * ray_rgba: [num_rays][4] attr type.  quantile_depths / quantile_point_indices:
+ * [num_rays][num_depth_quantiles] (NULL iff depth_quantiles NULL).  num_intersections may be
+ * NULL.  point_contribution: [num_points] attr type, zero-filled by the caller, or NULL. */
+int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *settings,
+                     uint32_t num_points, const float *points, const void *attributes,
+                     uint32_t point_adjacency_size, const uint32_t *point_adjacency,
+                     const uint32_t *point_adjacency_offsets, uint32_t num_rays,
+                     const float *rays, const uint32_t *start_point_index,
+                     uint32_t num_depth_quantiles, const float *depth_quantiles, void *ray_rgba,
+                     float *quantile_depths, uint32_t *quantile_point_indices,
+                     uint32_t *num_intersections, void *point_contribution,
+                     const rf_launch_opts *opts, void *stream);
+
+/* Pipeline::trace_backward, src/tracing/pipeline.h:80-100 (kernel: pipeline.cu:132-343).
+ * points_grad [num_points][3] f32, attribute_grad [num_points][A] attr type and point_error
+ * [num_points] attr type (optional) must be zero-filled by the caller (the reference binding
+ * does so, pipeline_bindings.cpp:441-452) and are accumulated into.  ray_grad is accepted for
+ * signature parity and, as in the reference, never written. */
+int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *settings,
+                      uint32_t num_points, const float *points, const void *attributes,
+                      uint32_t point_adjacency_size, const uint32_t *point_adjacency,
+                      const uint32_t *point_adjacency_offsets, uint32_t num_rays,
+                      const float *rays, const uint32_t *start_point_index,
+                      uint32_t num_depth_quantiles, const float *depth_quantiles,
+                      const uint32_t *quantile_point_indices, const void *ray_rgba,
+                      const void *ray_rgba_grad, const float *depth_grad, const void *ray_error,
+                      float *ray_grad, float *points_grad, void *attribute_grad,
+                      void *point_error, const rf_launch_opts *opts, void *stream);
+
+/* Pipeline::trace_benchmark, src/tracing/pipeline.h:117-126 (kernel: pipeline.cu:472-544).
+ * adjacent_diff is the CALLER's half4 table of point_adjacency_size entries (benchmark.py:44-54);
+ * camera is a HOST struct; start_point_index points at ONE device uint32; ray_rgba is
+ * uint32[height*width], RGBA8 packed as make_rgba8 (tracing_utils.cuh:105-115).
+ * The reference reads up to 3 table entries past the end of the last cell
+ * (tracing_utils.cuh:43-50); this implementation never reads past point_adjacency_size. */
+int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *settings,
+                       uint32_t num_points, const float *points, const void *attributes,
+                       uint32_t point_adjacency_size, const uint32_t *point_adjacency,
+                       const uint32_t *point_adjacency_offsets, const void *adjacent_diff,
+                       const rf_camera *camera, const uint32_t *start_point_index,
+                       uint32_t *ray_rgba, const rf_launch_opts *opts, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADFOAM_HIP_H */

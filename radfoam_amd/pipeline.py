@@ -1,0 +1,489 @@
+"""Host-side mirror of the reference's pipeline bindings.
+
+``create_pipeline`` / ``Pipeline.trace_forward`` / ``trace_backward`` / ``trace_benchmark`` have the
+names, argument order, defaults, validation messages and returned dict keys of
+/root/reference/torch_bindings/pipeline_bindings.cpp (cited per method), so that
+radfoam_model/render.py::TraceRays and scene.py call them unchanged.  The work itself is done
+by the HIP library behind the C-ABI of include/radfoam_hip.h; torch only provides device
+memory and the current stream.  There is no CPU path: CPU tensors are rejected with the
+reference's "... must be on CUDA device" errors.
+
+Differences from the reference, all documented in DESIGN.md:
+  * the packed foam (cell records + fp16 face table, what the reference rebuilds inside every
+    trace_forward AND trace_backward call, pipeline.cu:613-620,667-674) is cached on the
+    Pipeline while the input tensors are unchanged (same storage, same ``_version``);
+  * fp16 pipelines accumulate ``contribution`` / ``attr_grad`` / ``point_error`` in fp32 and
+    round once at the end;
+  * ``ray_grad`` is returned zero-filled (the reference returns uninitialised memory).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_DEFAULT_WEIGHT_THRESHOLD = 0.001  # default_trace_settings(), src/tracing/pipeline.h:15-20
+_DEFAULT_MAX_INTERSECTIONS = 1024
+
+
+def _parse_attr_dtype(attr_dtype):
+    """dtype_to_scalar_type(py::object), torch_bindings/bindings.h:24-42."""
+    s = str(attr_dtype)
+    if s in ("float32", "torch.float32"):
+        return torch.float32
+    if s in ("float16", "torch.float16"):
+        return torch.float16
+    if s in ("float64", "torch.float64"):
+        # parsed by the binding, rejected by create_pipeline (pipeline.cu:802-804)
+        raise RuntimeError("Unsupported attribute type")
+    raise RuntimeError(f"unsupported dtype '{s}'")
+
+
+def _dtype_name(dt) -> str:
+    return {torch.float32: "float32", torch.float16: "float16", torch.float64: "float64"}.get(dt, str(dt))
+
+
+def _c10_name(dt) -> str:
+    """c10::toString(ScalarType) for the dtypes that can show up in the messages."""
+    return {
+        torch.float32: "Float", torch.float64: "Double", torch.float16: "Half",
+        torch.bfloat16: "BFloat16", torch.int32: "Int", torch.int64: "Long",
+        torch.uint32: "UInt32", torch.uint8: "Byte", torch.int16: "Short", torch.bool: "Bool",
+    }.get(dt, str(dt))
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _FoamCache:
+    """One packed foam per Pipeline, keyed on the identity + version of the input tensors.
+
+    The entry keeps the input tensors alive, so their storage cannot be handed to a different
+    tensor while the entry could still be matched.
+    """
+
+    def __init__(self):
+        self.key = None
+        self.refs = None
+        self.workspace = None
+        self.diff_built = False
+
+    @staticmethod
+    def _key(tensors):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device) for t in tensors)
+
+    def lookup(self, tensors, need_diff):
+        if self.key is not None and self.key == self._key(tensors) and (self.diff_built or not need_diff):
+            return True
+        return False
+
+    def store(self, tensors, diff_built):
+        self.key = self._key(tensors)
+        self.refs = tuple(tensors)
+        self.diff_built = diff_built
+
+    def clear(self):
+        self.key = None
+        self.refs = None
+        self.diff_built = False
+
+
+class Pipeline:
+    """radfoam::Pipeline as seen from Python (pipeline_bindings.cpp:626-667)."""
+
+    def __init__(self, sh_degree: int, attr_dtype):
+        if not isinstance(sh_degree, int) or isinstance(sh_degree, bool):
+            raise TypeError("create_pipeline(): sh_degree must be an int")
+        self._attr_dtype = _parse_attr_dtype(attr_dtype)
+        if sh_degree < 0 or sh_degree > 3:
+            raise RuntimeError("Unsupported SH degree")  # pipeline.cu:787,800
+        self._lib = _lib.load()  # raises if the HIP library is not built: no fallback
+        self._sh_degree = sh_degree
+        self._attr_type = _lib.RF_ATTR_FLOAT16 if self._attr_dtype == torch.float16 else _lib.RF_ATTR_FLOAT32
+        self._attr_dim = int(self._lib.rf_attribute_dim(sh_degree))
+        self._cache = _FoamCache()
+        #: reuse the packed foam between calls while the inputs are unchanged
+        self.cache_foam = True
+        #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics (rf_launch_opts.backward_mode)
+        self.backward_mode = 0
+
+    # -- introspection (Pipeline::attribute_dim / attribute_type, pipeline.cu:768-774) ----------
+    def attribute_dim(self) -> int:
+        return self._attr_dim
+
+    def attribute_type(self):
+        return self._attr_dtype
+
+    @property
+    def sh_degree(self) -> int:
+        return self._sh_degree
+
+    # -- validation ----------------------------------------------------------------------------
+    def _validate_scene_data(self, points, attributes, point_adjacency, point_adjacency_offsets):
+        """validate_scene_data, pipeline_bindings.cpp:8-71."""
+        if points.size(-1) != 3:
+            raise RuntimeError(f"points had dimension {points.size(-1)} along axis -1, expected 3")
+        if points.dtype != torch.float32:
+            raise RuntimeError(f"points had dtype {_c10_name(points.dtype)}, expected float32")
+        if not points.is_cuda:
+            raise RuntimeError("points must be on CUDA device")
+        num_points = points.numel() // 3
+        if attributes.size(-1) != self._attr_dim:
+            raise RuntimeError(
+                f"attributes had dimension {attributes.size(-1)} along axis -1, expected {self._attr_dim}")
+        if attributes.numel() // self._attr_dim != num_points:
+            raise RuntimeError("attributes must have the same number of rows as points")
+        if attributes.dtype != self._attr_dtype:
+            raise RuntimeError(
+                f"attributes had dtype {_c10_name(attributes.dtype)}, expected {_dtype_name(self._attr_dtype)}")
+        if not attributes.is_cuda:
+            raise RuntimeError("attributes must be on CUDA device")
+        if point_adjacency_offsets.dtype != torch.uint32:
+            raise RuntimeError("point_adjacency_offsets must have uint32 dtype")
+        if not point_adjacency_offsets.is_cuda:
+            raise RuntimeError("point_adjacency_offsets must be on CUDA device")
+        if point_adjacency_offsets.numel() != num_points + 1:
+            raise RuntimeError("point_adjacency_offsets must have num_points + 1 elements")
+        if point_adjacency.dtype != torch.uint32:
+            raise RuntimeError("point_adjacency must have uint32 dtype")
+        if not point_adjacency.is_cuda:
+            raise RuntimeError("point_adjacency must be on CUDA device")
+
+    @staticmethod
+    def _validate_rays(rays, start_point):
+        """pipeline_bindings.cpp:139-159 / 304-324."""
+        if rays.size(-1) != 6:
+            raise RuntimeError("rays must have 6 as the last dimension")
+        if rays.dtype != torch.float32:
+            raise RuntimeError("rays must have float32 dtype")
+        if not rays.is_cuda:
+            raise RuntimeError("rays must be on CUDA device")
+        num_rays = rays.numel() // 6
+        if start_point.numel() != num_rays:
+            raise RuntimeError("start_point must have the same batch size as rays")
+        if start_point.dtype != torch.uint32:
+            raise RuntimeError("start_point must have uint32 dtype")
+        if not start_point.is_cuda:
+            raise RuntimeError("start_point must be on CUDA device")
+        return num_rays
+
+    @staticmethod
+    def _settings(weight_threshold, max_intersections):
+        s = _lib.TraceSettings(_DEFAULT_WEIGHT_THRESHOLD, _DEFAULT_MAX_INTERSECTIONS)
+        if weight_threshold is not None:
+            s.weight_threshold = float(weight_threshold)
+        if max_intersections is not None:
+            mi = int(max_intersections)
+            if mi < 0 or mi > 0xFFFFFFFF:
+                raise RuntimeError("max_intersections out of range for uint32")
+            s.max_intersections = mi
+        return s
+
+    # -- foam packing ---------------------------------------------------------------------------
+    def _launch_opts(self, points, attributes, adjacency, offsets, rays_shape, need_diff=True):
+        """Workspace + rf_launch_opts for this call; runs rf_prepare_foam on a cache miss."""
+        n = points.numel() // 3
+        e = adjacency.numel()
+        nbytes = int(self._lib.rf_workspace_bytes(n, e, self._sh_degree, self._attr_type))
+        tensors = (points, attributes, adjacency, offsets)
+        hit = self.cache_foam and self._cache.lookup(tensors, need_diff)
+        ws = self._cache.workspace
+        if ws is None or ws.numel() < nbytes or ws.device != points.device:
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=points.device)
+            self._cache.workspace = ws
+            hit = False
+        opts = _lib.LaunchOpts()
+        opts.workspace = ws.data_ptr()
+        opts.workspace_bytes = ws.numel()
+        opts.foam_prepared = 1 if hit else 0
+        opts.backward_mode = int(self.backward_mode)
+        # rays given as an image [H, W, 6]: let a wave own an 8x8 pixel tile
+        if len(rays_shape) == 3:
+            opts.image_height, opts.image_width = int(rays_shape[0]), int(rays_shape[1])
+        if not hit:
+            if self.cache_foam:
+                self._cache.store(tensors, diff_built=need_diff)
+            else:
+                self._cache.clear()
+        return opts
+
+    # -- trace_forward ---------------------------------------------------------------------------
+    def trace_forward(self, points, attributes, point_adjacency, point_adjacency_offsets, rays,
+                      start_point, depth_quantiles=None, weight_threshold=None,
+                      max_intersections=None, return_contribution=False):
+        """pipeline_bindings.cpp:107-265 (kernel: src/tracing/pipeline.cu:14-130)."""
+        points_c = points.contiguous()
+        attributes_c = attributes.contiguous()
+        adjacency_c = point_adjacency.contiguous()
+        offsets_c = point_adjacency_offsets.contiguous()
+        rays_c = rays.contiguous()
+        start_c = start_point.contiguous()
+        self._validate_scene_data(points, attributes, point_adjacency, point_adjacency_offsets)
+        num_points = points_c.size(0)
+        num_rays = self._validate_rays(rays_c, start_c)
+        dev = rays_c.device
+
+        nq = 0
+        quantiles_c = None
+        if depth_quantiles is not None:
+            quantiles_c = depth_quantiles.contiguous()
+            nq = quantiles_c.size(-1)
+            if quantiles_c.dtype != torch.float32:
+                raise RuntimeError("depth_quantiles must have float32 dtype")
+            if not quantiles_c.is_cuda:
+                raise RuntimeError("depth_quantiles must be on CUDA device")
+            if nq == 0 or quantiles_c.numel() // nq != num_rays:
+                raise RuntimeError("depth_quantiles must have the same batch size as rays")
+        settings = self._settings(weight_threshold, max_intersections)
+
+        batch = tuple(rays_c.shape[:-1])
+        rgba = torch.empty(batch + (4,), dtype=self._attr_dtype, device=dev)
+        num_intersections = torch.empty(batch + (1,), dtype=torch.uint32, device=dev)
+        contribution = None
+        if return_contribution:
+            contribution = torch.zeros((num_points, 1), dtype=torch.float32, device=dev)
+        depth = depth_indices = None
+        if quantiles_c is not None:
+            depth = torch.zeros(batch + (nq,), dtype=torch.float32, device=dev)
+            depth_indices = torch.zeros(batch + (nq,), dtype=torch.uint32, device=dev)
+
+        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
+        with torch.cuda.device(dev):
+            rc = self._lib.rf_trace_forward(
+                self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),
+                _ptr(attributes_c), adjacency_c.numel(), _ptr(adjacency_c), _ptr(offsets_c), num_rays,
+                _ptr(rays_c), _ptr(start_c), nq, _ptr(quantiles_c), _ptr(rgba), _ptr(depth),
+                _ptr(depth_indices), _ptr(num_intersections), _ptr(contribution), C.byref(opts),
+                _stream_ptr(dev))
+        _lib.check(rc)
+
+        out = {"rgba": rgba}
+        if quantiles_c is not None:
+            out["depth"] = depth
+            out["depth_indices"] = depth_indices
+        if return_contribution:
+            out["contribution"] = contribution.to(self._attr_dtype)
+        out["num_intersections"] = num_intersections
+        return out
+
+    # -- trace_backward --------------------------------------------------------------------------
+    def trace_backward(self, points, attributes, point_adjacency, point_adjacency_offsets, rays,
+                       start_point, rgb_out, grad_in, depth_quantiles=None, depth_indices=None,
+                       depth_grad_in=None, ray_error=None, weight_threshold=None,
+                       max_intersections=None):
+        """pipeline_bindings.cpp:267-497 (kernel: src/tracing/pipeline.cu:132-343)."""
+        points_c = points.contiguous()
+        attributes_c = attributes.contiguous()
+        adjacency_c = point_adjacency.contiguous()
+        offsets_c = point_adjacency_offsets.contiguous()
+        rays_c = rays.contiguous()
+        start_c = start_point.contiguous()
+        self._validate_scene_data(points, attributes, point_adjacency, point_adjacency_offsets)
+        num_points = points_c.size(0)
+        num_rays = self._validate_rays(rays_c, start_c)
+        dev = rays_c.device
+
+        grad_c = grad_in.contiguous()
+        if grad_c.size(-1) != 4:
+            raise RuntimeError("rgb_grad_in must have 4 as the last dimension")
+        if grad_c.dtype != self._attr_dtype:
+            raise RuntimeError(
+                f"rgb_grad_in had dtype {_c10_name(grad_c.dtype)}, expected {_dtype_name(self._attr_dtype)}")
+        if not grad_c.is_cuda:
+            raise RuntimeError("rgb_grad_in must be on CUDA device")
+        if grad_c.numel() // 4 != num_rays:
+            raise RuntimeError("rgb_grad_in must have the same batch size as rays")
+        # the reference passes rgb_out.data_ptr() unchecked (pipeline_bindings.cpp:479); a wrong
+        # dtype/size there is undefined behaviour, here it is an error
+        rgb_out_c = rgb_out.contiguous()
+        if rgb_out_c.dtype != self._attr_dtype or rgb_out_c.numel() != num_rays * 4 or not rgb_out_c.is_cuda:
+            raise RuntimeError("rgb_out must be the rgba returned by trace_forward for these rays")
+
+        nq = 0
+        quantiles_c = indices_c = depth_grad_c = None
+        if depth_quantiles is not None:
+            quantiles_c = depth_quantiles.contiguous()
+            nq = quantiles_c.size(-1)
+            if quantiles_c.dtype != torch.float32:
+                raise RuntimeError("depth_quantiles must have float32 dtype")
+            if not quantiles_c.is_cuda:
+                raise RuntimeError("depth_quantiles must be on CUDA device")
+            if quantiles_c.numel() != num_rays * nq:
+                raise RuntimeError("depth_quantiles must have the same batch size as rays")
+            if depth_grad_in is None:
+                raise RuntimeError("depth_grad must be provided if depth_quantiles is provided")
+            if depth_indices is None:
+                raise RuntimeError("depth_indices must be provided if depth_quantiles is provided")
+            indices_c = depth_indices.contiguous()
+            if indices_c.dtype != torch.uint32:
+                raise RuntimeError("depth_indices must have uint32 dtype")
+            if not indices_c.is_cuda:
+                raise RuntimeError("depth_indices must be on CUDA device")
+            if indices_c.numel() != num_rays * nq:
+                raise RuntimeError("depth_indices must have the same batch size as rays")
+            depth_grad_c = depth_grad_in.contiguous()
+            if depth_grad_c.size(-1) != nq:
+                raise RuntimeError(
+                    "depth_grad must have the same number of depth quantiles as depth_quantiles")
+            if depth_grad_c.dtype != torch.float32:
+                raise RuntimeError(f"depth_grad had dtype {_c10_name(depth_grad_c.dtype)}, expected float32")
+            if not depth_grad_c.is_cuda:
+                raise RuntimeError("depth_grad must be on CUDA device")
+            if depth_grad_c.numel() != num_rays * nq:
+                raise RuntimeError("depth_grad must have the same batch size as rays")
+
+        ray_error_c = point_error = None
+        if ray_error is not None:
+            ray_error_c = ray_error.contiguous()
+            if ray_error_c.dtype != self._attr_dtype:
+                raise RuntimeError(
+                    f"ray_error had dtype {_c10_name(ray_error_c.dtype)}, expected {_dtype_name(self._attr_dtype)}")
+            if not ray_error_c.is_cuda:
+                raise RuntimeError("ray_error must be on CUDA device")
+            if ray_error_c.numel() != num_rays:
+                raise RuntimeError("ray_error must have the same batch size as rays")
+            point_error = torch.zeros((num_points, 1), dtype=torch.float32, device=dev)
+        settings = self._settings(weight_threshold, max_intersections)
+
+        # one flat fp32 buffer [points_grad | attr_grad] so a data-parallel caller can all-reduce
+        # both with a single collective (radfoam_amd/dist.py)
+        a = self._attr_dim
+        flat = torch.zeros(num_points * (3 + a), dtype=torch.float32, device=dev)
+        points_grad = flat[: num_points * 3].view(num_points, 3)
+        attr_grad = flat[num_points * 3:].view(num_points, a)
+        ray_grad = torch.zeros_like(rays_c)
+
+        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
+        with torch.cuda.device(dev):
+            rc = self._lib.rf_trace_backward(
+                self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),
+                _ptr(attributes_c), adjacency_c.numel(), _ptr(adjacency_c), _ptr(offsets_c), num_rays,
+                _ptr(rays_c), _ptr(start_c), nq, _ptr(quantiles_c), _ptr(indices_c), _ptr(rgb_out_c),
+                _ptr(grad_c), _ptr(depth_grad_c), _ptr(ray_error_c), _ptr(ray_grad), _ptr(points_grad),
+                _ptr(attr_grad), _ptr(point_error), C.byref(opts), _stream_ptr(dev))
+        _lib.check(rc)
+
+        out = {
+            "points_grad": points_grad,
+            "attr_grad": attr_grad if self._attr_dtype == torch.float32 else attr_grad.to(self._attr_dtype),
+            "ray_grad": ray_grad,
+            # extra key (not in the reference): the flat fp32 [points_grad | attr_grad] buffer the
+            # two views above alias, for a single gradient all-reduce (radfoam_amd/dist.py)
+            "flat_grad": flat,
+        }
+        if ray_error is not None:
+            out["point_error"] = point_error.to(self._attr_dtype)
+        return out
+
+    # -- trace_benchmark -------------------------------------------------------------------------
+    def trace_benchmark(self, points, attributes, point_adjacency, point_adjacency_offsets,
+                        adjacent_diff, camera, start_point, output_rgba, weight_threshold=None,
+                        max_intersections=None):
+        """pipeline_bindings.cpp:499-585 (kernel: src/tracing/pipeline.cu:472-544)."""
+        points_c = points.contiguous()
+        attributes_c = attributes.contiguous()
+        adjacency_c = point_adjacency.contiguous()
+        offsets_c = point_adjacency_offsets.contiguous()
+        diff_c = adjacent_diff.contiguous()
+        self._validate_scene_data(points, attributes, point_adjacency, point_adjacency_offsets)
+        num_points = points_c.size(0)
+
+        cam = _lib.Camera()
+        for key in ("position", "forward", "up", "right"):
+            v = torch.as_tensor(camera[key]).detach().to("cpu", torch.float32).reshape(-1)
+            if v.numel() < 3:
+                raise RuntimeError(f"camera['{key}'] must have 3 elements")
+            setattr(cam, key, (C.c_float * 3)(float(v[0]), float(v[1]), float(v[2])))
+        cam.fov = float(camera["fov"])
+        cam.width = int(camera["width"])
+        cam.height = int(camera["height"])
+        model = camera["model"]
+        if model == "pinhole":
+            cam.model = 0
+        elif model == "fisheye":
+            cam.model = 1
+        else:
+            raise RuntimeError("Invalid camera model")
+
+        if start_point.numel() != 1:
+            raise RuntimeError("start_point must have a single element")
+        if start_point.dtype != torch.uint32:
+            raise RuntimeError("start_point must have uint32 dtype")
+        if not start_point.is_cuda:
+            raise RuntimeError("start_point must be on CUDA device")
+        if output_rgba.numel() != cam.width * cam.height:
+            raise RuntimeError("output_rgba must have width * height elements")
+        if output_rgba.dtype != torch.uint32:
+            raise RuntimeError("output_rgba must have uint32 dtype")
+        if not output_rgba.is_cuda:
+            raise RuntimeError("output_rgba must be on CUDA device")
+        # unchecked in the reference (reinterpret_cast of data_ptr, pipeline_bindings.cpp:581)
+        if diff_c.dtype != torch.float16 or not diff_c.is_cuda or diff_c.numel() < 4 * adjacency_c.numel():
+            raise RuntimeError("adjacent_diff must be a float16 CUDA tensor with 4 values per adjacency entry")
+        if not output_rgba.is_contiguous():
+            raise RuntimeError("output_rgba must be contiguous (it is written in place)")
+        settings = self._settings(weight_threshold, max_intersections)
+
+        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, (), need_diff=False)
+        dev = points_c.device
+        with torch.cuda.device(dev):
+            rc = self._lib.rf_trace_benchmark(
+                self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),
+                _ptr(attributes_c), adjacency_c.numel(), _ptr(adjacency_c), _ptr(offsets_c), _ptr(diff_c),
+                C.byref(cam), _ptr(start_point), _ptr(output_rgba), C.byref(opts), _stream_ptr(dev))
+        _lib.check(rc)
+        return None
+
+    # -- extras (no reference counterpart) -------------------------------------------------------
+    def walk_statistics(self, points, attributes, point_adjacency, point_adjacency_offsets, rays,
+                        start_point, weight_threshold=None, max_intersections=None):
+        """Exact walk counters of one forward pass (cells/faces scanned, hops, segments, lit
+        segments) -- the inputs of the algorithmic-bytes figure in bench.py."""
+        points_c, attributes_c = points.contiguous(), attributes.contiguous()
+        adjacency_c, offsets_c = point_adjacency.contiguous(), point_adjacency_offsets.contiguous()
+        rays_c, start_c = rays.contiguous(), start_point.contiguous()
+        self._validate_scene_data(points, attributes, point_adjacency, point_adjacency_offsets)
+        num_rays = self._validate_rays(rays_c, start_c)
+        dev = rays_c.device
+        settings = self._settings(weight_threshold, max_intersections)
+        stats = torch.zeros(8, dtype=torch.int64, device=dev)
+        rgba = torch.empty(tuple(rays_c.shape[:-1]) + (4,), dtype=self._attr_dtype, device=dev)
+        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
+        opts.stats = stats.data_ptr()
+        with torch.cuda.device(dev):
+            rc = self._lib.rf_trace_forward(
+                self._sh_degree, self._attr_type, C.byref(settings), points_c.size(0), _ptr(points_c),
+                _ptr(attributes_c), adjacency_c.numel(), _ptr(adjacency_c), _ptr(offsets_c), num_rays,
+                _ptr(rays_c), _ptr(start_c), 0, None, _ptr(rgba), None, None, None, None,
+                C.byref(opts), _stream_ptr(dev))
+        _lib.check(rc)
+        s = stats.cpu().tolist()
+        return {"cells_scanned": s[0], "faces_scanned": s[1], "hops": s[2], "segments": s[3],
+                "segments_lit": s[4], "num_rays": num_rays}
+
+    def build_adjacent_diff(self, points, point_adjacency, point_adjacency_offsets):
+        """half4 neighbour-offset table [E,4] (prefetch_adjacent_diff, pipeline.cu:546-586; the
+        table benchmark.py:44-54 builds in torch)."""
+        points_c = points.contiguous()
+        adjacency_c, offsets_c = point_adjacency.contiguous(), point_adjacency_offsets.contiguous()
+        if points_c.dtype != torch.float32 or not points_c.is_cuda:
+            raise RuntimeError("points must be a float32 CUDA tensor")
+        diff = torch.empty((adjacency_c.numel(), 4), dtype=torch.float16, device=points_c.device)
+        with torch.cuda.device(points_c.device):
+            rc = self._lib.rf_build_adjacent_diff(
+                _ptr(points_c), points_c.size(0), adjacency_c.numel(), _ptr(adjacency_c), _ptr(offsets_c),
+                _ptr(diff), _stream_ptr(points_c.device))
+        _lib.check(rc)
+        return diff
+
+
+def create_pipeline(sh_degree, attr_dtype="float32") -> Pipeline:
+    """radfoam.create_pipeline (pipeline_bindings.cpp:587-590,669-672; pipeline.cu:776-805)."""
+    return Pipeline(sh_degree, attr_dtype)

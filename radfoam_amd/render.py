@@ -1,0 +1,49 @@
+"""Autograd operator over the pipeline: same call signature and outputs as the reference's
+``radfoam_model.render.TraceRays`` (radfoam_model/render.py:10-122), so scene code written
+against the reference can use either.
+
+``TraceRays.apply(pipeline, points, attributes, point_adjacency, point_adjacency_offsets, rays,
+start_point, depth_quantiles, return_contribution)`` ->
+``(rgba, depth | None, contribution | None, num_intersections, errbox)``.
+Gradients flow to ``points`` and ``attributes`` only; non-finite gradient entries are zeroed
+after accumulation (render.py:98-99).  Setting ``errbox.ray_error`` before calling backward
+makes it deposit ``errbox.point_error`` (the densification statistic, scene.py:497-548).
+"""
+from __future__ import annotations
+
+import torch
+
+
+class ErrorBox:
+    def __init__(self):
+        self.ray_error = None
+        self.point_error = None
+
+
+class TraceRays(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pipeline, points, attributes, point_adjacency, point_adjacency_offsets, rays,
+                start_point, depth_quantiles, return_contribution):
+        out = pipeline.trace_forward(points, attributes, point_adjacency, point_adjacency_offsets, rays,
+                                     start_point, depth_quantiles=depth_quantiles,
+                                     return_contribution=return_contribution)
+        box = ErrorBox()
+        ctx.pipeline = pipeline
+        ctx.box = box
+        ctx.foam = (points, attributes, point_adjacency, point_adjacency_offsets)
+        ctx.ray_args = (rays, start_point, depth_quantiles)
+        ctx.fwd = (out["rgba"], out.get("depth_indices"))
+        return out["rgba"], out.get("depth"), out.get("contribution"), out["num_intersections"], box
+
+    @staticmethod
+    def backward(ctx, grad_rgba, grad_depth, _grad_contribution, _grad_count, _grad_box):
+        rays, start_point, depth_quantiles = ctx.ray_args
+        rgba, depth_indices = ctx.fwd
+        res = ctx.pipeline.trace_backward(*ctx.foam, rays, start_point, rgba, grad_rgba, depth_quantiles,
+                                          depth_indices, grad_depth, ctx.box.ray_error)
+        ctx.box.point_error = res.get("point_error")
+        points_grad, attr_grad = res["points_grad"], res["attr_grad"]
+        points_grad.masked_fill_(~points_grad.isfinite(), 0)
+        attr_grad.masked_fill_(~attr_grad.isfinite(), 0)
+        ctx.foam = ctx.ray_args = ctx.fwd = ctx.pipeline = None
+        return None, points_grad, attr_grad, None, None, None, None, None, None

@@ -1,0 +1,205 @@
+"""Names of the reference's ``radfoam`` module that sit beside the hot path.
+
+SURVEY.md section 8(b)/(f): the north star keeps the Delaunay build and the entry-cell lookup
+off the GPU "for now"; these are plain torch/scipy restatements so that the reference's
+radfoam_model/scene.py and data_loader import and run against this package.  They are NOT
+part of the measured path and make no performance claim.
+
+  Triangulation / TriangulationFailedError   torch_bindings/triangulation_bindings.cpp:225-237,222
+  build_aabb_tree                            :117-140
+  nn                                         :142-181
+  farthest_neighbor                          :183-217  (kernel: src/delaunay/triangulation_ops.cu:9-44)
+  BatchFetcher                               torch_bindings/torch_bindings.cpp:32-63,77-83
+  run_with_viewer / Viewer                   pipeline_bindings.cpp:592-624 (unsupported: no display)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import foam as _foam
+
+
+class TriangulationFailedError(RuntimeError):
+    """radfoam::TriangulationFailedError (registered at triangulation_bindings.cpp:222)."""
+
+
+class Triangulation:
+    """CPU (Qhull) stand-in for the reference's GPU Delaunay.
+
+    Same protocol as the reference class: construction kd-sorts the points and triangulates them
+    in that order; ``permutation()`` tells the caller how to reorder its own arrays;
+    ``rebuild(points)`` expects points already in that order and returns whether a new
+    permutation has to be applied.
+    """
+
+    def __init__(self, points: torch.Tensor):
+        if points.dim() != 2 or points.size(-1) != 3:
+            raise RuntimeError("points must have shape [N, 3]")
+        self._device = points.device
+        pts = points.detach().to("cpu", torch.float32).numpy()
+        if not np.isfinite(pts).all():
+            raise TriangulationFailedError("points contain non-finite values")
+        self._perm = _foam.kd_order(pts)
+        self._triangulate(np.ascontiguousarray(pts[self._perm]))
+
+    def _triangulate(self, pts_sorted: np.ndarray):
+        from scipy.spatial import Delaunay, QhullError
+
+        try:
+            tri = Delaunay(pts_sorted.astype(np.float64))
+        except QhullError as exc:  # degenerate input
+            raise TriangulationFailedError(str(exc)) from exc
+        indptr, indices = tri.vertex_neighbor_vertices
+        n = pts_sorted.shape[0]
+        if len(indptr) != n + 1 or (np.diff(indptr) == 0).any():
+            raise TriangulationFailedError("triangulation dropped points (duplicates or degenerate input)")
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+        order = np.lexsort((np.asarray(indices, dtype=np.int64), rows))
+        self._adjacency = np.asarray(indices, dtype=np.int64)[order].astype(np.uint32)
+        self._offsets = np.asarray(indptr, dtype=np.int64).astype(np.uint32)
+        self._tets = np.ascontiguousarray(tri.simplices.astype(np.uint32))
+        self._tet_adjacency = np.ascontiguousarray(tri.neighbors.astype(np.int64).astype(np.uint32))
+        self._vert_to_tet = np.ascontiguousarray(tri.vertex_to_simplex.astype(np.uint32))
+
+    def _t(self, a):
+        return torch.from_numpy(a).to(self._device)
+
+    def permutation(self):
+        return self._t(self._perm.astype(np.uint32))
+
+    def rebuild(self, points: torch.Tensor, incremental: bool = False) -> bool:
+        del incremental  # always a full rebuild
+        pts = points.detach().to("cpu", torch.float32).numpy()
+        if not np.isfinite(pts).all():
+            raise TriangulationFailedError("points contain non-finite values")
+        perm = _foam.kd_order(pts)
+        needs_permute = not np.array_equal(perm, np.arange(len(perm)))
+        self._perm = perm
+        self._triangulate(np.ascontiguousarray(pts[perm]))
+        return bool(needs_permute)
+
+    def point_adjacency(self):
+        return self._t(self._adjacency)
+
+    def point_adjacency_offsets(self):
+        return self._t(self._offsets)
+
+    def tets(self):
+        return self._t(self._tets)
+
+    def tet_adjacency(self):
+        return self._t(self._tet_adjacency)
+
+    def vert_to_tet(self):
+        return self._t(self._vert_to_tet)
+
+
+def build_aabb_tree(points: torch.Tensor) -> torch.Tensor:
+    """Tensor of the reference's shape [pow2_round_up(N), 2, 3].
+
+    Only ``nn`` consumes it, and this package's ``nn`` is an exact brute-force search, so the
+    tensor just carries the global bounding box (a valid, if useless, bound for every node).
+    """
+    if points.size(-1) != 3:
+        raise RuntimeError("points must have 3 as the last dimension")
+    if points.dim() != 2:
+        raise RuntimeError("points must have 2 dimensions")
+    n = points.size(0)
+    lo = points.min(dim=0).values
+    hi = points.max(dim=0).values
+    box = torch.stack([lo, hi], dim=0)
+    return box.unsqueeze(0).expand(_foam.pow2_round_up(n), 2, 3).contiguous()
+
+
+def nn(points: torch.Tensor, tree: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
+    """Index of the nearest point for every query (exact), uint32, shape queries.shape[:-1]."""
+    del tree
+    if points.dtype != queries.dtype:
+        raise RuntimeError("points and queries must have the same dtype")
+    q = queries.reshape(-1, 3).to(points.device)
+    out = torch.empty(q.size(0), dtype=torch.int64, device=points.device)
+    p = points.detach().double()
+    chunk = max(1, (1 << 24) // max(1, p.size(0)))
+    for i in range(0, q.size(0), chunk):
+        d = (p[None, :, :] - q[i:i + chunk, None, :].double()).square().sum(-1)
+        out[i:i + chunk] = d.argmin(dim=1)
+    return out.to(torch.uint32).reshape(queries.shape[:-1]).to(queries.device)
+
+
+def farthest_neighbor(points: torch.Tensor, point_adjacency: torch.Tensor,
+                      point_adjacency_offsets: torch.Tensor):
+    """(index of the farthest Delaunay neighbour, mean half-distance to the neighbours)."""
+    n = points.size(0)
+    off = point_adjacency_offsets.to(torch.int64)
+    adj = point_adjacency.to(torch.int64)
+    counts = off[1:] - off[:-1]
+    owner = torch.repeat_interleave(torch.arange(n, device=points.device), counts)
+    dist = (points[adj] - points[owner]).norm(dim=-1)
+    radius = torch.zeros(n, dtype=torch.float32, device=points.device)
+    radius.index_add_(0, owner, 0.5 * dist)
+    radius = radius / counts.to(torch.float32)
+    maxd = torch.full((n,), -1.0, dtype=dist.dtype, device=points.device)
+    maxd = maxd.scatter_reduce(0, owner, dist, reduce="amax", include_self=True)
+    is_max = dist == maxd[owner]
+    # first neighbour attaining the maximum (the reference keeps the first strict improvement)
+    pos = torch.arange(adj.numel(), device=points.device)
+    big = torch.full((n,), adj.numel(), dtype=torch.int64, device=points.device)
+    first = big.scatter_reduce(0, owner[is_max], pos[is_max], reduce="amin", include_self=True)
+    idx = adj[first.clamp(max=max(adj.numel() - 1, 0))]
+    return idx.to(torch.uint32), radius
+
+
+def _mix(x: np.ndarray) -> np.ndarray:
+    """hash-prospector mixer, src/utils/random.h:13-22 (uint32 arithmetic)."""
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(17)
+    x = (x * np.uint32(0xED5AD4BB)).astype(np.uint32)
+    x ^= x >> np.uint32(11)
+    x = (x * np.uint32(0xAC4C1B51)).astype(np.uint32)
+    x ^= x >> np.uint32(15)
+    x = (x * np.uint32(0x31848BAB)).astype(np.uint32)
+    x ^= x >> np.uint32(14)
+    return x
+
+
+class BatchFetcher:
+    """``BatchFetcher(data, batch_size, shuffle).next()`` -> device tensor [batch_size, ...].
+
+    Reproduces the reference's index sequence (src/utils/batch_fetcher.cpp:60-70): element j of
+    batch b is ``randint(make_rng(b*batch_size + j), 0, n)`` when shuffling, else
+    ``(b*batch_size + j) % n`` -- so parallel fetchers over rays / rgbs / alphas stay aligned.
+    The reference prefetches on a worker thread; this one gathers synchronously.
+    """
+
+    def __init__(self, data: torch.Tensor, batch_size: int, shuffle: bool):
+        self.data = data
+        self.batch_size = int(batch_size)
+        self.shuffle = bool(shuffle)
+        self.batch_idx = 0
+        self.device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+    def _indices(self) -> np.ndarray:
+        n = self.data.size(0)
+        base = np.arange(self.batch_size, dtype=np.uint64) + np.uint64(self.batch_idx) * np.uint64(self.batch_size)
+        if not self.shuffle:
+            return (base % np.uint64(n)).astype(np.int64)
+        seed = (base & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        with np.errstate(over="ignore"):
+            bits = _mix(seed ^ np.uint32(0x2815DB5B))
+        x = bits // np.uint32(0xFFFFFFFF // n)
+        return np.minimum(x, np.uint32(n - 1)).astype(np.int64)
+
+    def next(self) -> torch.Tensor:
+        idx = torch.from_numpy(self._indices())
+        self.batch_idx += 1
+        return self.data[idx.to(self.data.device)].to(self.device)
+
+
+class Viewer:
+    def __init__(self, *args, **kwargs):
+        raise RuntimeError("radfoam_amd: the interactive viewer is not supported (no display / GL)")
+
+
+def run_with_viewer(*args, **kwargs):
+    raise RuntimeError("radfoam_amd: the interactive viewer is not supported (no display / GL)")

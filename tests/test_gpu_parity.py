@@ -1,0 +1,272 @@
+"""-m gpu: the HIP path (through the radfoam boundary -> C-ABI) against the CPU oracle on the
+same seeded inputs.
+
+Tolerances (north star: 1e-4 RGB, 1e-3 relative gradient):
+  * forward outputs of fp32 pipelines -- rgba, depth, depth_indices, num_intersections -- must be
+    BIT-IDENTICAL to the oracle (both evaluate the same canonical fp32 arithmetic);
+  * scatter outputs (contribution, points_grad, attr_grad, point_error) are sums whose order
+    differs (atomics): rtol 1e-3 per element (helpers.grad_close), and 1e-5 relative L2.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _pipeline(d, dtype=torch.float32):
+    import radfoam
+
+    return radfoam.create_pipeline(d, dtype)
+
+
+def _run_forward(pipe, fm, rays, start, attr_dtype=None, **kw):
+    p, a, adj, off = H.to_torch_foam(fm, DEV, attr_dtype)
+    r = torch.from_numpy(rays).to(DEV)
+    if np.ndim(start) == 0:
+        s = torch.full(r.shape[:-1], int(start), dtype=torch.int64).to(torch.uint32).to(DEV)
+    else:
+        s = torch.from_numpy(np.asarray(start, dtype=np.uint32)).to(DEV)
+    if "depth_quantiles" in kw and kw["depth_quantiles"] is not None:
+        kw["depth_quantiles"] = torch.from_numpy(kw["depth_quantiles"]).to(DEV)
+    out = pipe.trace_forward(p, a, adj, off, r, s, **kw)
+    torch.cuda.synchronize()
+    return {k: v.cpu() for k, v in out.items()}, (p, a, adj, off, r, s)
+
+
+@pytest.mark.parametrize("d", [0, 1, 2, 3])
+def test_forward_image_bit_exact(foam_factory, d):
+    fm = foam_factory(6000, d, 11)
+    cam, rays, start = H.camera_setup(fm, 96, 64)
+    ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                          fm["point_adjacency_offsets"], rays, start)
+    got, _ = _run_forward(_pipeline(d), fm, rays, start)
+    assert got["rgba"].shape == (64, 96, 4) and got["num_intersections"].shape == (64, 96, 1)
+    np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
+    np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+    assert ref["rgba"][..., 3].max() > 0.5  # the scene is actually hit
+
+
+@pytest.mark.parametrize("d", [0, 2, 3])
+def test_forward_flat_rays_quantiles_contribution(foam_factory, d):
+    fm = foam_factory(6000, d, 12)
+    rays, starts = H.random_rays(fm, 5000, seed=3)
+    rng = np.random.default_rng(5)
+    q = np.sort(rng.uniform(0.02, 0.98, size=(5000, 2)).astype(np.float32), axis=1)[:, ::-1].copy()
+    ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                          fm["point_adjacency_offsets"], rays, starts, depth_quantiles=q,
+                          return_contribution=True, num_threads=1)
+    got, _ = _run_forward(_pipeline(d), fm, rays, starts, depth_quantiles=q, return_contribution=True)
+    np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
+    np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+    np.testing.assert_array_equal(got["depth_indices"].numpy().view(np.uint32), ref["depth_indices"])
+    np.testing.assert_array_equal(got["depth"].numpy().view(np.uint32), ref["depth"].view(np.uint32))
+    assert (ref["depth_indices"] == 0xFFFFFFFF).any() and (ref["depth_indices"] != 0xFFFFFFFF).any()
+    ok, rel, worst = H.grad_close(got["contribution"].numpy(), ref["contribution"])
+    assert ok and rel < 1e-5, (rel, worst)
+    # invariant: sum of weights == sum of alpha
+    assert abs(float(got["contribution"].double().sum()) - float(got["rgba"][..., 3].double().sum())) < 1e-2
+
+
+@pytest.mark.parametrize("d", [0, 1, 2, 3])
+def test_forward_half_attributes(foam_factory, d):
+    fm = foam_factory(6000, d, 13)
+    fm16 = dict(fm)
+    fm16["attributes"] = fm["attributes"].astype(np.float16)
+    cam, rays, start = H.camera_setup(fm, 64, 48)
+    ref = O.trace_forward(d, fm16["points"], fm16["attributes"], fm16["point_adjacency"],
+                          fm16["point_adjacency_offsets"], rays, start, return_contribution=True)
+    got, _ = _run_forward(_pipeline(d, torch.float16), fm16, rays, start, return_contribution=True)
+    assert got["rgba"].dtype == torch.float16 and got["contribution"].dtype == torch.float16
+    np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
+    np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint16), ref["rgba"].view(np.uint16))
+    np.testing.assert_allclose(got["contribution"].float().numpy(), ref["contribution"].astype(np.float32),
+                               rtol=2e-3, atol=1e-3)
+
+
+def test_forward_settings_and_edge_cases(foam_factory):
+    d = 1
+    fm = foam_factory(6000, d, 14)
+    cam, rays, start = H.camera_setup(fm, 40, 30)
+    pipe = _pipeline(d)
+    for thr, mi in [(0.05, None), (None, 7), (0.3, 3), (None, 0)]:
+        ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                              fm["point_adjacency_offsets"], rays, start, weight_threshold=thr,
+                              max_intersections=mi)
+        got, _ = _run_forward(pipe, fm, rays, start, weight_threshold=thr, max_intersections=mi)
+        np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
+        np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+    # rays pointing away from the foam from outside: leave through the first (unbounded) cell
+    away = rays.copy()
+    away[..., 3:] *= -1.0
+    ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                          fm["point_adjacency_offsets"], away, start)
+    got, _ = _run_forward(pipe, fm, away, start)
+    np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
+    np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+    assert float(got["rgba"].abs().max()) == 0.0
+    # empty batch
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    out = pipe.trace_forward(p, a, adj, off, torch.zeros((0, 6), device=DEV),
+                             torch.zeros((0,), dtype=torch.uint32, device=DEV))
+    assert out["rgba"].shape == (0, 4)
+
+
+def _backward_case(foam_factory, d, seed, image, quantiles, with_error, n_points=5000):
+    fm = foam_factory(n_points, d, seed)
+    rng = np.random.default_rng(seed)
+    if image:
+        cam, rays, start = H.camera_setup(fm, 80, 56)
+        starts = np.full(rays.shape[:-1], start, dtype=np.uint32)
+    else:
+        rays, starts = H.random_rays(fm, 4000, seed=seed + 1)
+    batch = rays.shape[:-1]
+    q = dg = None
+    if quantiles:
+        q = np.sort(rng.uniform(0.02, 0.98, size=batch + (2,)).astype(np.float32), axis=-1)[..., ::-1].copy()
+        dg = rng.normal(size=batch + (2,)).astype(np.float32)
+    g = rng.normal(size=batch + (4,)).astype(np.float32)
+    err = rng.uniform(0, 1, size=batch).astype(np.float32) if with_error else None
+    args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    fwd = O.trace_forward(*args, rays, starts, depth_quantiles=q)
+    ref = O.trace_backward(*args, rays, starts, fwd["rgba"], g, depth_quantiles=q,
+                           depth_indices=fwd.get("depth_indices"), depth_grad_in=dg, ray_error=err,
+                           num_threads=1)
+    return fm, rays, starts, q, dg, g, err, fwd, ref
+
+
+@pytest.mark.parametrize("mode", [1])
+@pytest.mark.parametrize("d,image,quantiles,with_error", [
+    (0, True, False, False), (1, False, True, True), (2, True, True, False), (2, False, False, True),
+    (3, True, False, False), (3, False, True, True),
+])
+def test_backward_parity(foam_factory, d, image, quantiles, with_error, mode):
+    fm, rays, starts, q, dg, g, err, fwd, ref = _backward_case(foam_factory, d, 20 + d, image, quantiles, with_error)
+    pipe = _pipeline(d)
+    pipe.backward_mode = mode
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    t = lambda x: None if x is None else torch.from_numpy(x).to(DEV)
+    out = pipe.trace_backward(p, a, adj, off, t(rays), t(starts), t(fwd["rgba"]), t(g), t(q),
+                              t(fwd.get("depth_indices")), t(dg), t(err))
+    torch.cuda.synchronize()
+    assert out["points_grad"].shape == (fm["points"].shape[0], 3)
+    assert out["attr_grad"].shape == fm["attributes"].shape
+    assert out["ray_grad"].shape == rays.shape
+    for key in ["points_grad", "attr_grad"] + (["point_error"] if with_error else []):
+        ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+        assert ok and rel < 1e-5, (key, rel, worst)
+        assert np.abs(ref[key]).max() > 0
+
+
+def test_autograd_operator_matches_oracle(foam_factory):
+    """TraceRays (radfoam_amd/render.py) end to end, incl. the non-finite scrub."""
+    from radfoam_amd.render import TraceRays
+
+    d = 2
+    fm, rays, starts, q, dg, g, err, fwd, ref = _backward_case(foam_factory, d, 31, True, True, False)
+    pipe = _pipeline(d)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    p.requires_grad_(True)
+    a.requires_grad_(True)
+    r = torch.from_numpy(rays).to(DEV)
+    s = torch.from_numpy(starts).to(DEV)
+    rgba, depth, contrib, nint, box = TraceRays.apply(pipe, p, a, adj, off, r, s, torch.from_numpy(q).to(DEV), False)
+    np.testing.assert_array_equal(rgba.detach().cpu().numpy().view(np.uint32), fwd["rgba"].view(np.uint32))
+    loss = (rgba * torch.from_numpy(g).to(DEV)).sum() + (depth * torch.from_numpy(dg).to(DEV)).sum()
+    loss.backward()
+    for got, key in [(p.grad, "points_grad"), (a.grad, "attr_grad")]:
+        refg = np.where(np.isfinite(ref[key]), ref[key], 0.0)
+        ok, rel, worst = H.grad_close(got.cpu().numpy(), refg)
+        assert ok and rel < 1e-5, (key, rel, worst)
+
+
+@pytest.mark.parametrize("d,half", [(0, False), (2, True), (3, True), (1, False)])
+def test_benchmark_path(foam_factory, d, half):
+    fm = foam_factory(6000, d, 40 + d)
+    if half:
+        fm = dict(fm)
+        fm["attributes"] = fm["attributes"].astype(np.float16)
+    cam, _, start = H.camera_setup(fm, 100, 60)
+    diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    ref = O.trace_benchmark(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                            fm["point_adjacency_offsets"], diff, cam, start, weight_threshold=0.05)
+    pipe = _pipeline(d, torch.float16 if half else torch.float32)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    # the table exactly as benchmark.py builds it, without padding
+    dtab = pipe.build_adjacent_diff(p, adj, off)
+    np.testing.assert_array_equal(dtab.cpu().numpy().view(np.uint16), diff)
+    out = torch.zeros((60, 100), dtype=torch.uint32, device=DEV)
+    camera = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    sp = torch.tensor([int(start)], dtype=torch.int64).to(torch.uint32).to(DEV)
+    pipe.trace_benchmark(p, a, adj, off, dtab, camera, sp, out, weight_threshold=0.05)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), ref)
+    # fisheye: device sin/cos/atan2 differ from glibc by ulps -> channels within 1 LSB
+    cam_f = dict(cam)
+    cam_f["model"] = "fisheye"
+    cam_f["fov"] = 1.2
+    ref_f = O.trace_benchmark(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                              fm["point_adjacency_offsets"], diff, cam_f, start, weight_threshold=0.05)
+    camera["model"], camera["fov"] = "fisheye", 1.2
+    pipe.trace_benchmark(p, a, adj, off, dtab, camera, sp, out, weight_threshold=0.05)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    gb = np.stack([(got >> s) & 0xFF for s in (0, 8, 16, 24)], -1).astype(np.int32)
+    rb = np.stack([(ref_f >> s) & 0xFF for s in (0, 8, 16, 24)], -1).astype(np.int32)
+    assert np.abs(gb - rb).max() <= 1 and (np.abs(gb - rb) > 0).mean() < 0.02
+
+
+def test_foam_cache_invalidation(foam_factory):
+    """The packed-foam cache must notice in-place updates and new tensors."""
+    d = 0
+    fm = foam_factory(6000, d, 50)
+    cam, rays, start = H.camera_setup(fm, 32, 32)
+    pipe = _pipeline(d)
+    got1, (p, a, adj, off, r, s) = _run_forward(pipe, fm, rays, start)
+    with torch.no_grad():
+        a[:, -1] *= 0.5  # in-place: bumps _version
+    out2 = pipe.trace_forward(p, a, adj, off, r, s)
+    fm2 = dict(fm)
+    fm2["attributes"] = fm["attributes"].copy()
+    fm2["attributes"][:, -1] *= 0.5
+    ref2 = O.trace_forward(d, fm2["points"], fm2["attributes"], fm2["point_adjacency"],
+                           fm2["point_adjacency_offsets"], rays, start)
+    np.testing.assert_array_equal(out2["rgba"].cpu().numpy().view(np.uint32), ref2["rgba"].view(np.uint32))
+    assert not np.array_equal(got1["rgba"].numpy(), ref2["rgba"])
+
+
+def test_large_image_properties(foam_factory):
+    """Bigger workload (not oracle-sized): size-independent properties."""
+    d = 2
+    fm = foam_factory(60000, d, 60)
+    cam, rays, start = H.camera_setup(fm, 640, 360)
+    pipe = _pipeline(d)
+    got, (p, a, adj, off, r, s) = _run_forward(pipe, fm, rays, start, return_contribution=True)
+    rgba = got["rgba"].double()
+    assert torch.isfinite(rgba).all() and float(rgba[..., 3].max()) <= 1.0 and float(rgba.min()) >= 0.0
+    # sum of per-cell weights == sum of per-ray alpha
+    assert abs(float(got["contribution"].double().sum()) - float(rgba[..., 3].sum())) < 1e-3 * float(rgba[..., 3].sum())
+    assert int(got["num_intersections"].to(torch.int64).max()) <= 1025
+    # forward is deterministic and independent of the ray->lane mapping (image tiles vs flat list)
+    flat = pipe.trace_forward(p, a, adj, off, r.reshape(-1, 6), s.reshape(-1))
+    assert torch.equal(flat["rgba"].cpu().reshape(360, 640, 4), got["rgba"])
+    # a sampled sub-image agrees bit-for-bit with the oracle
+    sub = rays[::9, ::16]
+    ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                          fm["point_adjacency_offsets"], sub, start)
+    np.testing.assert_array_equal(got["rgba"].numpy()[::9, ::16].view(np.uint32), ref["rgba"].view(np.uint32))
+    # backward is linear in the incoming gradient
+    g1 = torch.randn(360, 640, 4, device=DEV)
+    g2 = torch.randn(360, 640, 4, device=DEV)
+    rg = got["rgba"].to(DEV)
+    b1 = pipe.trace_backward(p, a, adj, off, r, s, rg, g1)
+    b2 = pipe.trace_backward(p, a, adj, off, r, s, rg, g2)
+    b12 = pipe.trace_backward(p, a, adj, off, r, s, rg, g1 + g2)
+    for k in ("points_grad", "attr_grad"):
+        ok, rel, worst = H.grad_close((b1[k] + b2[k]).cpu().numpy(), b12[k].cpu().numpy())
+        assert rel < 1e-4, (k, rel)

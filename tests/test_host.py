@@ -1,0 +1,191 @@
+"""CPU: the host-side mirror of the reference boundary and the C-ABI library (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for fn in os.listdir(inc):
+        if fn.endswith(".h"):
+            text = open(os.path.join(inc, fn)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            names |= set(re.findall(r"\b(rf_[a-z_0-9]+)\s*\(", text))
+    return names
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from radfoam_amd import _lib
+
+    declared = _declared_symbols()
+    assert {"rf_trace_forward", "rf_trace_backward", "rf_trace_benchmark", "rf_prepare_foam",
+            "rf_build_adjacent_diff", "rf_workspace_bytes", "rf_last_error", "rf_attribute_dim"} <= declared
+    assert declared == set(_lib.SYMBOLS), "ctypes table and include/radfoam_hip.h disagree"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+    _lib.load()
+
+
+def test_struct_layouts_match_header():
+    from radfoam_amd import _lib
+
+    assert ctypes.sizeof(_lib.TraceSettings) == 8
+    assert ctypes.sizeof(_lib.Camera) == 4 * 12 + 4 + 4 * 3
+    assert _lib.LaunchOpts.workspace.offset == 0 and _lib.LaunchOpts.workspace_bytes.offset == 8
+    assert _lib.LaunchOpts.foam_prepared.offset == 16 and _lib.LaunchOpts.stats.offset == 32
+    assert ctypes.sizeof(_lib.LaunchOpts) == 40
+
+
+def test_host_only_entry_points():
+    from radfoam_amd import _lib
+
+    lib = _lib.load()
+    assert [lib.rf_attribute_dim(d) for d in range(-1, 5)] == [0, 4, 13, 28, 49, 0]
+    n, e = 1000, 15500
+    # cells + (E+32)*8 face table (+ repacked SH rows when the row pitch is not 16-B aligned)
+    base = 32 * n + 8 * (e + 32)
+    assert base <= lib.rf_workspace_bytes(n, e, 2, 0) < base + 1024
+    assert lib.rf_workspace_bytes(n, e, 1, 0) >= base + n * 12 * 4
+    assert lib.rf_workspace_bytes(n, e, 3, 1) >= base + n * 48 * 2
+    assert lib.rf_workspace_bytes(n, e, 7, 0) == 0 and lib.rf_workspace_bytes(n, e, 2, 5) == 0
+    # argument errors are reported without touching a device
+    s = _lib.TraceSettings(1e-3, 1024)
+    o = _lib.LaunchOpts()
+    rc = lib.rf_trace_forward(9, 0, ctypes.byref(s), 0, None, None, 0, None, None, 0, None, None, 0, None,
+                              None, None, None, None, None, ctypes.byref(o), None)
+    assert rc == -1 and "Unsupported SH degree" in _lib.last_error()
+    rc = lib.rf_trace_forward(2, 0, ctypes.byref(s), 10, None, None, 0, None, None, 5, None, None, 0, None,
+                              None, None, None, None, None, ctypes.byref(o), None)
+    assert rc == -1 and "null pointer" in _lib.last_error()
+
+
+def test_create_pipeline_dtype_and_degree_rules():
+    import radfoam
+
+    for d, a in [(0, 4), (1, 13), (2, 28), (3, 49)]:
+        assert radfoam.create_pipeline(d).attribute_dim() == a
+    assert radfoam.create_pipeline(1, "float16").attribute_type() == torch.float16
+    assert radfoam.create_pipeline(1, torch.float16).attribute_type() == torch.float16
+    assert radfoam.create_pipeline(1, "torch.float32").attribute_type() == torch.float32
+    with pytest.raises(RuntimeError, match="Unsupported SH degree"):
+        radfoam.create_pipeline(4)
+    with pytest.raises(RuntimeError, match="Unsupported attribute type"):
+        radfoam.create_pipeline(1, torch.float64)
+    with pytest.raises(RuntimeError, match="unsupported dtype"):
+        radfoam.create_pipeline(1, torch.int32)
+
+
+def _cpu_inputs(n=10, a=28, r=4):
+    return dict(
+        points=torch.zeros(n, 3), attributes=torch.zeros(n, a),
+        point_adjacency=torch.zeros(5, dtype=torch.uint32),
+        point_adjacency_offsets=torch.zeros(n + 1, dtype=torch.uint32),
+        rays=torch.zeros(r, 6), start_point=torch.zeros(r, dtype=torch.uint32))
+
+
+def test_validation_mirrors_reference_messages():
+    """No CPU fallback: CPU tensors are rejected exactly like the reference binding does
+    (pipeline_bindings.cpp:8-71); shape/dtype errors come first, in the reference's order."""
+    import radfoam
+
+    pipe = radfoam.create_pipeline(2)
+    kw = _cpu_inputs()
+    with pytest.raises(RuntimeError, match="points must be on CUDA device"):
+        pipe.trace_forward(**kw)
+    bad = dict(kw, points=torch.zeros(10, 4))
+    with pytest.raises(RuntimeError, match="points had dimension 4 along axis -1, expected 3"):
+        pipe.trace_forward(**bad)
+    bad = dict(kw, points=torch.zeros(10, 3, dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="points had dtype Double, expected float32"):
+        pipe.trace_forward(**bad)
+    with pytest.raises(RuntimeError, match="points must be on CUDA device"):
+        pipe.trace_backward(rgb_out=torch.zeros(4, 4), grad_in=torch.zeros(4, 4), **kw)
+    with pytest.raises(RuntimeError, match="points must be on CUDA device"):
+        pipe.trace_benchmark(kw["points"], kw["attributes"], kw["point_adjacency"], kw["point_adjacency_offsets"],
+                             torch.zeros(5, 4, dtype=torch.float16), {}, torch.zeros(1, dtype=torch.uint32),
+                             torch.zeros(4, dtype=torch.uint32))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from radfoam_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under radfoam_amd/ or radfoam/ may import, link,
+    load or execute it."""
+    pat = re.compile(r"(^\s*(from|import)\s+oracle\b)|liboracle|oracle[/\\.]|rfo_", re.M)
+    for pkg in ("radfoam_amd", "radfoam"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".hpp", ".h")):
+                    text = open(os.path.join(dirpath, fn)).read()
+                    assert not pat.search(text), f"{pkg}/{fn} references the oracle"
+
+
+def test_shims_nn_farthest_neighbor_batchfetcher_triangulation():
+    import radfoam
+
+    rng = np.random.default_rng(0)
+    pts = torch.from_numpy(rng.uniform(-1, 1, size=(500, 3)).astype(np.float32))
+    tri = radfoam.Triangulation(pts)
+    perm = tri.permutation().to(torch.long)
+    assert sorted(perm.tolist()) == list(range(500))
+    pts = pts[perm]
+    assert tri.rebuild(pts) is False  # already in kd-order
+    adj, off = tri.point_adjacency(), tri.point_adjacency_offsets()
+    assert adj.dtype == torch.uint32 and off.dtype == torch.uint32 and off.numel() == 501
+    assert int(off[-1]) == adj.numel()
+    # symmetric graph
+    o = off.to(torch.int64)
+    owner = torch.repeat_interleave(torch.arange(500), o[1:] - o[:-1])
+    edges = set(zip(owner.tolist(), adj.to(torch.int64).tolist()))
+    assert all((b, a) in edges for a, b in edges)
+    tree = radfoam.build_aabb_tree(pts)
+    assert tuple(tree.shape) == (512, 2, 3)
+    q = torch.from_numpy(rng.uniform(-1, 1, size=(7, 3)).astype(np.float32))
+    got = radfoam.nn(pts, tree, q).to(torch.int64)
+    exp = ((pts[None] - q[:, None]) ** 2).sum(-1).argmin(1)
+    assert torch.equal(got, exp)
+    far, rad = radfoam.farthest_neighbor(pts, adj, off)
+    for i in (0, 17, 499):
+        nb = adj[o[i]:o[i + 1]].to(torch.int64)
+        dist = (pts[nb] - pts[i]).norm(dim=-1)
+        assert int(far[i]) == int(nb[dist.argmax()])
+        assert abs(float(rad[i]) - float(0.5 * dist.mean())) < 1e-6
+    with pytest.raises(radfoam.TriangulationFailedError):
+        radfoam.Triangulation(torch.zeros(10, 3))
+    data = torch.arange(100, dtype=torch.float32).reshape(50, 2)
+    f1, f2 = radfoam.BatchFetcher(data, 8, True), radfoam.BatchFetcher(data[:, :1].clone(), 8, True)
+    b1, b2 = f1.next().cpu(), f2.next().cpu()
+    assert b1.shape == (8, 2) and torch.equal(b1[:, :1], b2)  # aligned shuffles
+    seq = radfoam.BatchFetcher(data, 8, False)
+    assert torch.equal(seq.next().cpu(), data[:8]) and torch.equal(seq.next().cpu(), data[8:16])
+
+
+def test_foam_generator_contract():
+    from radfoam_amd import foam
+
+    fm = foam.make_synthetic_foam(1500, 1, 2)
+    assert fm["points"].dtype == np.float32 and fm["attributes"].shape == (1500, 13)
+    off = fm["point_adjacency_offsets"].astype(np.int64)
+    assert off[0] == 0 and off[-1] == len(fm["point_adjacency"]) and (np.diff(off) >= 3).all()
+    for i in (0, 700, 1499):
+        row = fm["point_adjacency"][off[i]:off[i + 1]]
+        assert (np.diff(row.astype(np.int64)) > 0).all()  # ascending, no duplicates
+    r = np.linalg.norm(fm["points"], axis=1)
+    assert (fm["attributes"][r > 0.8, -1] == 0).all() and (fm["attributes"][r < 0.79, -1] > 0).all()
+    again = foam.make_synthetic_foam(1500, 1, 2)
+    assert np.array_equal(again["points"], fm["points"]) and np.array_equal(again["attributes"], fm["attributes"])
