@@ -111,6 +111,27 @@ inline uint32_t grid_blocks(const RayGrid &g) {
     return (g.num_rays + 255u) / 256u;
 }
 
+
+// One packed cell record, fetched as two naturally aligned 16-byte loads.
+struct CellRec {
+    float x, y, z, s;
+    uint32_t begin, end;
+};
+
+__device__ __forceinline__ CellRec load_cell(const RfCell *cells, uint32_t i) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(cells) + 2 * (size_t)i;
+    uint4 a = q[0];
+    uint4 b = q[1];
+    CellRec c;
+    c.x = bits2f(a.x);
+    c.y = bits2f(a.y);
+    c.z = bits2f(a.z);
+    c.s = bits2f(a.w);
+    c.begin = b.x;
+    c.end = b.y;
+    return c;
+}
+
 // ------------------------------------------------------------------------------------------
 // the per-cell face scan                         reference: trace<>, tracing_utils.cuh:27-67
 
@@ -256,40 +277,48 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 
 // ------------------------------------------------------------------------------------------
 // forward / benchmark                     reference: pipeline.cu:14-130 and :472-544
+//
+// Control flow: every lane keeps an `alive` flag and the wave iterates while any lane is alive
+// (no per-lane `break` out of nested conditionals).  hipcc 7.2 was observed to miscompile the
+// natural `for(;;){...break...}` form of this loop (the next cell's face range was dropped on
+// the path through the compositing block); the flag form also is what lane compaction needs.
 
 template <int DEG, bool HALF, bool BENCH>
 __global__ __launch_bounds__(256) void forward_kernel(FwdParams p) {
     uint32_t ray;
-    if (!map_ray(p.grid, ray)) return;
+    bool alive = map_ray(p.grid, ray);
     const FoamView &fv = p.foam;
 
-    float Ox, Oy, Oz, dx, dy, dz;
-    uint32_t cur;
-    if constexpr (BENCH) {
-        uint32_t pi = ray % p.cam.width, pj = ray / p.cam.width;
-        Ox = p.cam.position[0];
-        Oy = p.cam.position[1];
-        Oz = p.cam.position[2];
-        cast_ray(p.cam, p.inv_tan_half_fov, pi, pj, dx, dy, dz);
-        if (sqrtf(dot3(dx, dy, dz, dx, dy, dz)) < 0.1f) {
-            p.rgba8[ray] = 0u;
-            return;
+    float Ox = 0.0f, Oy = 0.0f, Oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 1.0f;
+    uint32_t cur = 0;
+    if (alive) {
+        if constexpr (BENCH) {
+            uint32_t pi = ray % p.cam.width, pj = ray / p.cam.width;
+            Ox = p.cam.position[0];
+            Oy = p.cam.position[1];
+            Oz = p.cam.position[2];
+            cast_ray(p.cam, p.inv_tan_half_fov, pi, pj, dx, dy, dz);
+            if (sqrtf(dot3(dx, dy, dz, dx, dy, dz)) < 0.1f) {
+                p.rgba8[ray] = 0u;
+                alive = false;
+            }
+            cur = p.start[0];
+        } else {
+            const float *rp = p.rays + (size_t)ray * 6;
+            Ox = rp[0];
+            Oy = rp[1];
+            Oz = rp[2];
+            dx = rp[3];
+            dy = rp[4];
+            dz = rp[5];
+            float nrm = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+            dx = dx / nrm;
+            dy = dy / nrm;
+            dz = dz / nrm;
+            cur = p.start[ray];
         }
-        cur = p.start[0];
-    } else {
-        const float *rp = p.rays + (size_t)ray * 6;
-        Ox = rp[0];
-        Oy = rp[1];
-        Oz = rp[2];
-        dx = rp[3];
-        dy = rp[4];
-        dz = rp[5];
-        float nrm = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
-        dx = dx / nrm;
-        dy = dy / nrm;
-        dz = dz / nrm;
-        cur = p.start[ray];
     }
+    const bool valid = alive;  // lanes that own a ray and must write outputs
     float sh[sh_dim(DEG)];
     sh_basis<DEG>(dx, dy, dz, sh);
 
@@ -298,7 +327,7 @@ __global__ __launch_bounds__(256) void forward_kernel(FwdParams p) {
     const uint32_t nq = BENCH ? 0u : p.nq;
     const float *qp = nullptr;
     float cq = 0.0f;
-    if (nq) {
+    if (nq && alive) {
         qp = p.quantiles + (size_t)ray * nq;
         cq = qp[0];
     }
@@ -310,59 +339,62 @@ __global__ __launch_bounds__(256) void forward_kernel(FwdParams p) {
 
     float t0 = 0.0f;
     uint32_t n = 0;
-    const float4 *c4 = reinterpret_cast<const float4 *>(fv.cells);
-    float4 head = c4[2 * (size_t)cur];
-    uint2 span = *reinterpret_cast<const uint2 *>(c4 + 2 * (size_t)cur + 1);
-    for (;;) {
-        n++;
-        if (n > max_steps) break;
-        float t1;
-        uint32_t best;
-        scan_cell<BENCH>(fv, span.x, span.y, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, t1, best);
-        if (want_stats) {
-            st_cells++;
-            st_faces += span.y - span.x;
+    CellRec head = load_cell(fv.cells, cur);
+    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+        if (alive) {
+            n++;
+            if (n > max_steps) alive = false;
         }
-        if (best == kNone) break;
-        uint32_t nxt = fv.adj[best];
-        float4 nhead = c4[2 * (size_t)nxt];
-        uint2 nspan = *reinterpret_cast<const uint2 *>(c4 + 2 * (size_t)nxt + 1);
-        if (want_stats) st_hops++;
-        if (t1 > t0) {
-            float s = head.w;
-            float r = 0.0f, g = 0.0f, b = 0.0f;
-            if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
+        float t1 = __builtin_inff();
+        uint32_t best = kNone;
+        if (alive) {
+            scan_cell<BENCH>(fv, head.begin, head.end, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, t1, best);
             if (want_stats) {
-                st_seg++;
-                st_lit += (s > 1e-6f) ? 1u : 0u;
+                st_cells++;
+                st_faces += head.end - head.begin;
             }
-            float dt = __builtin_fmaxf(t1 - t0, 0.0f);
-            float alpha = 1.0f - exp_(-s * dt);
-            float w = T * alpha;
-            if constexpr (!BENCH) {
-                if (p.contribution) unsafeAtomicAdd(p.contribution + cur, w);
-            }
-            Cr = fma_(w, r, Cr);
-            Cg = fma_(w, g, Cg);
-            Cb = fma_(w, b, Cb);
-            float Tn = T * (1.0f - alpha);
-            if constexpr (!BENCH) {
-                while (qi < nq && Tn < cq) {
-                    p.qdepth[(size_t)ray * nq + qi] = t0 + log_(T / cq) / s;
-                    p.qidx[(size_t)ray * nq + qi] = cur;
-                    qi++;
-                    if (qi < nq) cq = qp[qi];
-                }
-            }
-            T = Tn;
-            if (!(T > thr)) break;
+            if (best == kNone) alive = false;
         }
-        t0 = __builtin_fmaxf(t0, t1);
-        cur = nxt;
-        head = nhead;
-        span = nspan;
+        if (alive) {
+            const uint32_t nxt = fv.adj[best];
+            const CellRec nhead = load_cell(fv.cells, nxt);
+            if (want_stats) st_hops++;
+            if (t1 > t0) {
+                float s = head.s;
+                float r = 0.0f, g = 0.0f, b = 0.0f;
+                if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
+                if (want_stats) {
+                    st_seg++;
+                    st_lit += (s > 1e-6f) ? 1u : 0u;
+                }
+                float dt = __builtin_fmaxf(t1 - t0, 0.0f);
+                float alpha = 1.0f - exp_(-s * dt);
+                float w = T * alpha;
+                if constexpr (!BENCH) {
+                    if (p.contribution) unsafeAtomicAdd(p.contribution + cur, w);
+                }
+                Cr = fma_(w, r, Cr);
+                Cg = fma_(w, g, Cg);
+                Cb = fma_(w, b, Cb);
+                float Tn = T * (1.0f - alpha);
+                if constexpr (!BENCH) {
+                    while (qi < nq && Tn < cq) {
+                        p.qdepth[(size_t)ray * nq + qi] = t0 + log_(T / cq) / s;
+                        p.qidx[(size_t)ray * nq + qi] = cur;
+                        qi++;
+                        if (qi < nq) cq = qp[qi];
+                    }
+                }
+                T = Tn;
+                if (!(T > thr)) alive = false;
+            }
+            t0 = __builtin_fmaxf(t0, t1);
+            cur = nxt;
+            head = nhead;
+        }
     }
 
+    if (!valid) return;
     if constexpr (BENCH) {
         p.rgba8[ray] = make_rgba8(Cr, Cg, Cb, 1.0f);
     } else {
@@ -410,52 +442,57 @@ __device__ __forceinline__ float load_attr_scalar(const void *base, size_t i) {
 template <int DEG, bool HALF>
 __global__ __launch_bounds__(256) void backward_kernel(BwdParams p) {
     uint32_t ray;
-    if (!map_ray(p.grid, ray)) return;
+    bool alive = map_ray(p.grid, ray);
     const FoamView &fv = p.foam;
     constexpr int NB = sh_dim(DEG);
     constexpr int A = 1 + 3 * NB;
 
-    const float *rp = p.rays + (size_t)ray * 6;
-    float Ox = rp[0], Oy = rp[1], Oz = rp[2];
-    float dx = rp[3], dy = rp[4], dz = rp[5];
-    {
-        float nrm = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
-        dx = dx / nrm;
-        dy = dy / nrm;
-        dz = dz / nrm;
-    }
-    float sh[NB];
-    sh_basis<DEG>(dx, dy, dz, sh);
-
-    float gr = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 0);
-    float gg = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 1);
-    float gb = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 2);
-    float ga = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 3);
-    float outr = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 0);
-    float outg = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 1);
-    float outb = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 2);
-    float outa = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 3);
+    float Ox = 0.0f, Oy = 0.0f, Oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 1.0f;
+    float gr = 0.0f, gg = 0.0f, gb = 0.0f, ga = 0.0f, outr = 0.0f, outg = 0.0f, outb = 0.0f, outa = 0.0f;
     float err = 0.0f;
-    if (p.ray_error) err = load_attr_scalar<HALF>(p.ray_error, ray);
-
+    uint32_t cur = 0;
     const uint32_t nq = p.nq;
     uint32_t qi = 0;
     const float *qp = nullptr;
     const float *dgp = nullptr;
     float cq = 0.0f, cdg = 0.0f;
-    const float4 *c4 = reinterpret_cast<const float4 *>(fv.cells);
-    if (nq) {
-        qp = p.quantiles + (size_t)ray * nq;
-        dgp = p.depth_grad + (size_t)ray * nq;
-        cq = qp[0];
-        for (uint32_t i = 0; i < nq; ++i) {
-            uint32_t ci = p.qidx[(size_t)ray * nq + i];
-            if (ci != kNone) {
-                float s = c4[2 * (size_t)ci].w;
-                cdg += dgp[i] / s;
+    if (alive) {
+        const float *rp = p.rays + (size_t)ray * 6;
+        Ox = rp[0];
+        Oy = rp[1];
+        Oz = rp[2];
+        dx = rp[3];
+        dy = rp[4];
+        dz = rp[5];
+        float nrm = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        dx = dx / nrm;
+        dy = dy / nrm;
+        dz = dz / nrm;
+        gr = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 0);
+        gg = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 1);
+        gb = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 2);
+        ga = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 3);
+        outr = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 0);
+        outg = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 1);
+        outb = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 2);
+        outa = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 3);
+        if (p.ray_error) err = load_attr_scalar<HALF>(p.ray_error, ray);
+        cur = p.start[ray];
+        if (nq) {
+            qp = p.quantiles + (size_t)ray * nq;
+            dgp = p.depth_grad + (size_t)ray * nq;
+            cq = qp[0];
+            for (uint32_t i = 0; i < nq; ++i) {
+                uint32_t ci = p.qidx[(size_t)ray * nq + i];
+                if (ci != kNone) {
+                    float s = load_cell(fv.cells, ci).s;
+                    cdg += dgp[i] / s;
+                }
             }
         }
     }
+    float sh[NB];
+    sh_basis<DEG>(dx, dy, dz, sh);
     const float thr = p.settings.weight_threshold;
     const uint32_t max_steps = p.settings.max_intersections;
 
@@ -468,121 +505,123 @@ __global__ __launch_bounds__(256) void backward_kernel(BwdParams p) {
 
     float t0 = 0.0f;
     uint32_t n = 0;
-    uint32_t cur = p.start[ray];
-    float4 head = c4[2 * (size_t)cur];
-    uint2 span = *reinterpret_cast<const uint2 *>(c4 + 2 * (size_t)cur + 1);
-    for (;;) {
-        n++;
-        if (n > max_steps) break;
-        float t1;
-        uint32_t best;
-        scan_cell<false>(fv, span.x, span.y, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, t1, best);
-        if (best == kNone) break;
-        uint32_t nxt = fv.adj[best];
-        float4 nhead = c4[2 * (size_t)nxt];
-        uint2 nspan = *reinterpret_cast<const uint2 *>(c4 + 2 * (size_t)nxt + 1);
-        if (t1 > t0) {
-            float s = head.w;
-            float r = 0.0f, g = 0.0f, b = 0.0f;
-            if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
-            float dt = __builtin_fmaxf(t1 - t0, 0.0f);
-            float alpha = 1.0f - exp_(-s * dt);
-            float w = T * alpha;
-            float da_ds = dt * (1.0f - alpha);
-            float da_ddt = (dt > 0.0f) ? s * (1.0f - alpha) : 0.0f;
-
-            Cr = fma_(w, r, Cr);
-            Cg = fma_(w, g, Cg);
-            Cb = fma_(w, b, Cb);
-            if (p.point_error) unsafeAtomicAdd(p.point_error + cur, w * err);
-
-            float dLr = gr * w, dLg = gg * w, dLb = gb * w;
-            float den = T * ((1.0f - alpha) + 1e-6f);
-            float dfr = r - (outr - Cr) / den;
-            float dfg = g - (outg - Cg) / den;
-            float dfb = b - (outb - Cb) / den;
-            float dL_da = T * dot3(dfr, dfg, dfb, gr, gg, gb);
-            dL_da = dL_da + ((1.0f - outa) * ga) / ((1.0f - alpha) + 1e-6f);
-
-            float dL_ds = dL_da * da_ds;
-            float dL_ddt = dL_da * da_ddt;
-            float dL_dt0 = 0.0f;
-
-            float Tn = T * (1.0f - alpha);
-            while (qi < nq && Tn < cq) {
-                float gi = dgp[qi] / s;
-                dL_dt0 = dL_dt0 + gi;
-                dL_ds = dL_ds + ((-gi) * log_(T / cq)) / s;
-                cdg = cdg - gi;
-                qi++;
-                if (qi < nq) cq = qp[qi];
-            }
-            if (qi < nq) {
-                dL_ds = fma_(-dt, cdg, dL_ds);
-                dL_ddt = fma_(-s, cdg, dL_ddt);
-            }
-            dL_dt0 = dL_dt0 + (-dL_ddt);
-            float dL_dt1 = dL_ddt;
-
-            float ax = 0.0f, ay = 0.0f, az = 0.0f;  // dt0_dprev
-            if (prev != kNone)
-                bisector_grad(ppx, ppy, ppz, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, ax, ay, az);
-            float bx, by, bz;                        // dt1_dcurrent
-            bisector_grad(head.x, head.y, head.z, nhead.x, nhead.y, nhead.z, Ox, Oy, Oz, dx, dy, dz, bx, by, bz);
-            float ex, ey, ez;                        // dt0_dcurrent (vs prev, or vs origin on the first segment)
-            bisector_grad(head.x, head.y, head.z, ppx, ppy, ppz, Ox, Oy, Oz, dx, dy, dz, ex, ey, ez);
-            float fx, fy, fz;                        // dt1_dnext
-            bisector_grad(nhead.x, nhead.y, nhead.z, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, fx, fy, fz);
-
-            pgx = fma_(dL_dt0, ax, pgx);
-            pgy = fma_(dL_dt0, ay, pgy);
-            pgz = fma_(dL_dt0, az, pgz);
-            cgx = cgx + fma_(dL_dt0, ex, dL_dt1 * bx);
-            cgy = cgy + fma_(dL_dt0, ey, dL_dt1 * by);
-            cgz = cgz + fma_(dL_dt0, ez, dL_dt1 * bz);
-            ngx = fma_(dL_dt1, fx, ngx);
-            ngy = fma_(dL_dt1, fy, ngy);
-            ngz = fma_(dL_dt1, fz, ngz);
-
-            if (prev != kNone) {
-                float *pg = p.points_grad + 3 * (size_t)prev;
-                unsafeAtomicAdd(pg + 0, pgx);
-                unsafeAtomicAdd(pg + 1, pgy);
-                unsafeAtomicAdd(pg + 2, pgz);
-            }
-            ppx = head.x;
-            ppy = head.y;
-            ppz = head.z;
-            prev = cur;
-            pgx = cgx;
-            pgy = cgy;
-            pgz = cgz;
-            cgx = ngx;
-            cgy = ngy;
-            cgz = ngz;
-            ngx = ngy = ngz = 0.0f;
-            T = Tn;
-
-            if (r == 0.0f) dLr = 0.0f;
-            if (g == 0.0f) dLg = 0.0f;
-            if (b == 0.0f) dLb = 0.0f;
-            float *row = p.attr_grad + (size_t)cur * A;
-            // all-zero colour gradients (empty cells, clamped channels) add nothing: skip them
-            if (dLr != 0.0f || dLg != 0.0f || dLb != 0.0f) {
-#pragma unroll
-                for (int i = 0; i < 3 * NB; ++i) {
-                    float gc = (i % 3 == 0) ? dLr : ((i % 3 == 1) ? dLg : dLb);
-                    unsafeAtomicAdd(row + i, sh[i / 3] * gc);
-                }
-            }
-            unsafeAtomicAdd(row + (A - 1), dL_ds);
-
-            if (!(T > thr)) break;
+    CellRec head = load_cell(fv.cells, cur);
+    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+        if (alive) {
+            n++;
+            if (n > max_steps) alive = false;
         }
-        t0 = __builtin_fmaxf(t0, t1);
-        cur = nxt;
-        head = nhead;
-        span = nspan;
+        float t1 = __builtin_inff();
+        uint32_t best = kNone;
+        if (alive) {
+            scan_cell<false>(fv, head.begin, head.end, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, t1, best);
+            if (best == kNone) alive = false;
+        }
+        if (alive) {
+            const uint32_t nxt = fv.adj[best];
+            const CellRec nhead = load_cell(fv.cells, nxt);
+            if (t1 > t0) {
+                float s = head.s;
+                float r = 0.0f, g = 0.0f, b = 0.0f;
+                if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
+                float dt = __builtin_fmaxf(t1 - t0, 0.0f);
+                float alpha = 1.0f - exp_(-s * dt);
+                float w = T * alpha;
+                float da_ds = dt * (1.0f - alpha);
+                float da_ddt = (dt > 0.0f) ? s * (1.0f - alpha) : 0.0f;
+
+                Cr = fma_(w, r, Cr);
+                Cg = fma_(w, g, Cg);
+                Cb = fma_(w, b, Cb);
+                if (p.point_error) unsafeAtomicAdd(p.point_error + cur, w * err);
+
+                float dLr = gr * w, dLg = gg * w, dLb = gb * w;
+                float den = T * ((1.0f - alpha) + 1e-6f);
+                float dfr = r - (outr - Cr) / den;
+                float dfg = g - (outg - Cg) / den;
+                float dfb = b - (outb - Cb) / den;
+                float dL_da = T * dot3(dfr, dfg, dfb, gr, gg, gb);
+                dL_da = dL_da + ((1.0f - outa) * ga) / ((1.0f - alpha) + 1e-6f);
+
+                float dL_ds = dL_da * da_ds;
+                float dL_ddt = dL_da * da_ddt;
+                float dL_dt0 = 0.0f;
+
+                float Tn = T * (1.0f - alpha);
+                while (qi < nq && Tn < cq) {
+                    float gi = dgp[qi] / s;
+                    dL_dt0 = dL_dt0 + gi;
+                    dL_ds = dL_ds + ((-gi) * log_(T / cq)) / s;
+                    cdg = cdg - gi;
+                    qi++;
+                    if (qi < nq) cq = qp[qi];
+                }
+                if (qi < nq) {
+                    dL_ds = fma_(-dt, cdg, dL_ds);
+                    dL_ddt = fma_(-s, cdg, dL_ddt);
+                }
+                dL_dt0 = dL_dt0 + (-dL_ddt);
+                float dL_dt1 = dL_ddt;
+
+                float ax = 0.0f, ay = 0.0f, az = 0.0f;  // dt0_dprev
+                if (prev != kNone)
+                    bisector_grad(ppx, ppy, ppz, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, ax, ay, az);
+                float bx, by, bz;                        // dt1_dcurrent
+                bisector_grad(head.x, head.y, head.z, nhead.x, nhead.y, nhead.z, Ox, Oy, Oz, dx, dy, dz, bx, by, bz);
+                float ex, ey, ez;                        // dt0_dcurrent (vs prev, or vs origin on the first segment)
+                bisector_grad(head.x, head.y, head.z, ppx, ppy, ppz, Ox, Oy, Oz, dx, dy, dz, ex, ey, ez);
+                float fx, fy, fz;                        // dt1_dnext
+                bisector_grad(nhead.x, nhead.y, nhead.z, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, fx, fy, fz);
+
+                pgx = fma_(dL_dt0, ax, pgx);
+                pgy = fma_(dL_dt0, ay, pgy);
+                pgz = fma_(dL_dt0, az, pgz);
+                cgx = cgx + fma_(dL_dt0, ex, dL_dt1 * bx);
+                cgy = cgy + fma_(dL_dt0, ey, dL_dt1 * by);
+                cgz = cgz + fma_(dL_dt0, ez, dL_dt1 * bz);
+                ngx = fma_(dL_dt1, fx, ngx);
+                ngy = fma_(dL_dt1, fy, ngy);
+                ngz = fma_(dL_dt1, fz, ngz);
+
+                if (prev != kNone) {
+                    float *pg = p.points_grad + 3 * (size_t)prev;
+                    unsafeAtomicAdd(pg + 0, pgx);
+                    unsafeAtomicAdd(pg + 1, pgy);
+                    unsafeAtomicAdd(pg + 2, pgz);
+                }
+                ppx = head.x;
+                ppy = head.y;
+                ppz = head.z;
+                prev = cur;
+                pgx = cgx;
+                pgy = cgy;
+                pgz = cgz;
+                cgx = ngx;
+                cgy = ngy;
+                cgz = ngz;
+                ngx = ngy = ngz = 0.0f;
+                T = Tn;
+
+                if (r == 0.0f) dLr = 0.0f;
+                if (g == 0.0f) dLg = 0.0f;
+                if (b == 0.0f) dLb = 0.0f;
+                float *row = p.attr_grad + (size_t)cur * A;
+                // all-zero colour gradients (empty cells, clamped channels) add nothing: skip them
+                if (dLr != 0.0f || dLg != 0.0f || dLb != 0.0f) {
+#pragma unroll
+                    for (int i = 0; i < 3 * NB; ++i) {
+                        float gc = (i % 3 == 0) ? dLr : ((i % 3 == 1) ? dLg : dLb);
+                        unsafeAtomicAdd(row + i, sh[i / 3] * gc);
+                    }
+                }
+                unsafeAtomicAdd(row + (A - 1), dL_ds);
+
+                if (!(T > thr)) alive = false;
+            }
+            t0 = __builtin_fmaxf(t0, t1);
+            cur = nxt;
+            head = nhead;
+        }
     }
 }
 
