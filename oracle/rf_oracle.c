@@ -296,18 +296,14 @@ void rfo_trace_forward(int sh_degree, int attr_half, rfo_settings settings, uint
                      attr_half ? attr_f : (const float *)attributes, adj, offsets,
                      diff ? diff : diff_own};
     int nt = pick_threads(num_threads);
-    float *contrib_tl = NULL;
-    if (contribution) contrib_tl = (float *)calloc((size_t)nt * num_points, sizeof(float));
+    /* scatter output: ONE fp32 accumulator shared by all threads (omp atomic), like the GPU's */
+    float *contrib_f = NULL;
+    if (contribution) contrib_f = (float *)calloc(num_points ? num_points : 1, sizeof(float));
     rfo_stats total = {0, 0, 0, 0, 0};
 #pragma omp parallel num_threads(nt)
     {
-        int tid = 0;
-#ifdef _OPENMP
-        tid = omp_get_thread_num();
-#endif
         rfo_stats local = {0, 0, 0, 0, 0};
-        float *contrib = contrib_tl ? contrib_tl + (size_t)tid * num_points : NULL;
-#pragma omp for schedule(static)
+#pragma omp for schedule(dynamic, 64)
         for (int64_t r = 0; r < (int64_t)num_rays; ++r) {
             float out[4];
             float qd[64];
@@ -315,7 +311,7 @@ void rfo_trace_forward(int sh_degree, int attr_half, rfo_settings settings, uint
             uint32_t nqq = nq > 64 ? 64 : nq;
             uint32_t n = forward_ray_f32(&fm, rays + 6 * r, start[r], nqq,
                                          quantiles ? quantiles + (size_t)r * nq : NULL, out, qd, qx,
-                                         contrib, 1, stats ? &local : NULL);
+                                         contrib_f, 1, stats ? &local : NULL, nt > 1);
             for (int c = 0; c < 4; ++c) store_attr(rgba, 4 * (size_t)r + c, out[c], attr_half);
             for (uint32_t i = 0; i < nqq; ++i) {
                 qdepth[(size_t)r * nq + i] = qd[i];
@@ -333,12 +329,8 @@ void rfo_trace_forward(int sh_degree, int attr_half, rfo_settings settings, uint
         }
     }
     if (contribution) {
-        for (size_t i = 0; i < num_points; ++i) {
-            float s = 0.0f;
-            for (int t = 0; t < nt; ++t) s += contrib_tl[(size_t)t * num_points + i];
-            store_attr(contribution, i, s, attr_half);
-        }
-        free(contrib_tl);
+        for (size_t i = 0; i < num_points; ++i) store_attr(contribution, i, contrib_f[i], attr_half);
+        free(contrib_f);
     }
     if (stats) *stats = total;
     free(attr_f);
@@ -381,43 +373,25 @@ void rfo_trace_backward(int sh_degree, int attr_half, rfo_settings settings, uin
     const float *err_p = ray_error ? (attr_half ? err_f : (const float *)ray_error) : NULL;
 
     int nt = pick_threads(num_threads);
+    /* ONE set of fp32 accumulators shared by all threads (omp atomic): what a many-core CPU
+     * implementation would do; per-thread copies cost nt*N*(4+A) floats to zero and reduce */
     size_t per = (size_t)num_points * (3 + A + 1);
-    float *tl = (float *)calloc((size_t)nt * per, sizeof(float));
-#pragma omp parallel num_threads(nt)
-    {
-        int tid = 0;
-#ifdef _OPENMP
-        tid = omp_get_thread_num();
-#endif
-        float *pg = tl + (size_t)tid * per;
-        float *ag = pg + (size_t)num_points * 3;
-        float *pe = ag + (size_t)num_points * A;
-#pragma omp for schedule(static)
-        for (int64_t r = 0; r < (int64_t)num_rays; ++r) {
-            backward_ray_f32(&fm, rays + 6 * r, start[r], nq,
-                             quantiles ? quantiles + (size_t)r * nq : NULL,
-                             qidx ? qidx + (size_t)r * nq : NULL, rgba_p + 4 * r, g_p + 4 * r,
-                             depth_grad ? depth_grad + (size_t)r * nq : NULL,
-                             err_p ? err_p + r : NULL, pg, ag, point_error ? pe : NULL, strict);
-        }
+    float *tl = (float *)calloc(per ? per : 1, sizeof(float));
+    float *pg = tl;
+    float *ag = pg + (size_t)num_points * 3;
+    float *pe = ag + (size_t)num_points * A;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+    for (int64_t r = 0; r < (int64_t)num_rays; ++r) {
+        backward_ray_f32(&fm, rays + 6 * r, start[r], nq,
+                         quantiles ? quantiles + (size_t)r * nq : NULL,
+                         qidx ? qidx + (size_t)r * nq : NULL, rgba_p + 4 * r, g_p + 4 * r,
+                         depth_grad ? depth_grad + (size_t)r * nq : NULL,
+                         err_p ? err_p + r : NULL, pg, ag, point_error ? pe : NULL, strict, nt > 1);
     }
-    for (size_t i = 0; i < (size_t)num_points * 3; ++i) {
-        float s = 0.0f;
-        for (int t = 0; t < nt; ++t) s += tl[(size_t)t * per + i];
-        points_grad[i] = s;
-    }
-    for (size_t i = 0; i < (size_t)num_points * A; ++i) {
-        float s = 0.0f;
-        for (int t = 0; t < nt; ++t) s += tl[(size_t)t * per + (size_t)num_points * 3 + i];
-        store_attr(attr_grad, i, s, attr_half);
-    }
-    if (point_error) {
-        for (size_t i = 0; i < num_points; ++i) {
-            float s = 0.0f;
-            for (int t = 0; t < nt; ++t) s += tl[(size_t)t * per + (size_t)num_points * (3 + A) + i];
-            store_attr(point_error, i, s, attr_half);
-        }
-    }
+    memcpy(points_grad, pg, sizeof(float) * 3 * (size_t)num_points);
+    for (size_t i = 0; i < (size_t)num_points * A; ++i) store_attr(attr_grad, i, ag[i], attr_half);
+    if (point_error)
+        for (size_t i = 0; i < num_points; ++i) store_attr(point_error, i, pe[i], attr_half);
     free(tl);
     free(attr_f);
     free(rgba_f);
@@ -520,7 +494,7 @@ void rfo_trace_benchmark(int sh_degree, int attr_half, rfo_settings settings, ui
             out_rgba8[idx] = 0;
             continue;
         }
-        forward_ray_f32(&fm, ray, start_point, 0, NULL, out, NULL, NULL, NULL, 0, NULL);
+        forward_ray_f32(&fm, ray, start_point, 0, NULL, out, NULL, NULL, NULL, 0, NULL, 0);
         out_rgba8[idx] = make_rgba8(out[0], out[1], out[2], 1.0f);
     }
     free(attr_f);
@@ -540,7 +514,7 @@ void rfo_trace_forward_f64(int sh_degree, rfo_settings settings, uint32_t num_po
         uint32_t n = forward_ray_f64(&fm, rays + 6 * (size_t)r, start[r], nq,
                                      quantiles ? quantiles + (size_t)r * nq : NULL,
                                      rgba + 4 * (size_t)r, qdepth ? qdepth + (size_t)r * nq : NULL,
-                                     qidx ? qidx + (size_t)r * nq : NULL, contribution, 1, NULL);
+                                     qidx ? qidx + (size_t)r * nq : NULL, contribution, 1, NULL, 0);
         if (num_intersections) num_intersections[r] = n;
     }
 }
@@ -565,6 +539,6 @@ void rfo_trace_backward_f64(int sh_degree, rfo_settings settings, uint32_t num_p
                          rgba_grad + 4 * (size_t)r,
                          depth_grad ? depth_grad + (size_t)r * nq : NULL,
                          ray_error ? ray_error + r : NULL, points_grad, attr_grad, point_error,
-                         strict);
+                         strict, 0);
     }
 }
