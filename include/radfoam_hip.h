@@ -58,6 +58,7 @@ typedef struct rf_launch_opts {
     void *workspace;          /* device scratch, >= rf_workspace_bytes(); holds the packed foam      */
     size_t workspace_bytes;
     uint32_t foam_prepared;   /* 1: workspace already holds rf_prepare_foam() output for these inputs */
+                              /*   (for rf_trace_benchmark: prepared WITH the same adjacent_diff)     */
     uint32_t image_width;     /* rays form a row-major [image_height, image_width] grid: lets a wave  */
     uint32_t image_height;    /*   own an 8x8 pixel tile.  0,0 = treat rays as a flat list            */
     uint32_t backward_mode;   /* rf_trace_backward only: 0 = auto, 1 = per-lane atomics, 2 = wave     */
@@ -73,10 +74,11 @@ const char *rf_last_error(void);
 /* Pipeline::attribute_dim(), pipeline.cu:768-770: 1 + 3*(d+1)^2, or 0 if d is unsupported. */
 uint32_t rf_attribute_dim(int sh_degree);
 
-/* Bytes of device scratch the tracer needs for a foam of this size (packed cell records,
- * fp16 face-offset table with the reference's +32 pad, repacked SH rows when the attribute
- * row is not 16-byte aligned).  Replaces the per-call CUDAArray<Vec4h>(E+32) of
- * pipeline.cu:613,667. */
+/* Bytes of device scratch the tracer needs for a foam of this size: 16-byte cell records,
+ * the 16-byte-per-face table (fp16 neighbour offsets as in the reference's half4 table, plus
+ * the neighbour index and its face range) with the reference's +32 entries of slack, and
+ * repacked SH rows when the attribute row is not 16-byte aligned.  Replaces the per-call
+ * CUDAArray<Vec4h>(E+32) of pipeline.cu:613,667. */
 size_t rf_workspace_bytes(uint32_t num_points, uint32_t point_adjacency_size, int sh_degree,
                           int attr_type);
 
@@ -88,21 +90,24 @@ int rf_build_adjacent_diff(const float *points, uint32_t num_points,
                            const uint32_t *point_adjacency_offsets, void *adjacent_diff,
                            void *stream);
 
-/* Packs the foam into `workspace` for the walk kernels: cell records {x,y,z,density,begin,end},
- * the fp16 face-offset table (same values as rf_build_adjacent_diff) and aligned SH rows.
+/* Packs the foam into `workspace` for the walk kernels: cell records {x,y,z,density}, the face
+ * table (fp16 offsets with the same values as rf_build_adjacent_diff, or taken verbatim from
+ * `adjacent_diff` when that is not NULL) and aligned SH rows.
  * The reference does the equivalent (prefetch_adjacent_diff) inside every trace_forward /
  * trace_backward call (pipeline.cu:613-620,667-674); here the result may be reused while
  * points/attributes/adjacency are unchanged (opts->foam_prepared). */
 int rf_prepare_foam(int sh_degree, int attr_type, uint32_t num_points, const float *points,
                     const void *attributes, uint32_t point_adjacency_size,
                     const uint32_t *point_adjacency, const uint32_t *point_adjacency_offsets,
-                    void *workspace, size_t workspace_bytes, void *stream);
+                    const void *adjacent_diff, void *workspace, size_t workspace_bytes,
+                    void *stream);
 
 /* Pipeline::trace_forward, src/tracing/pipeline.h:62-78 (kernel: pipeline.cu:14-130).
  * rays: [num_rays][6] (origin, direction; direction is normalised in the kernel).
  * ray_rgba: [num_rays][4] attr type.  quantile_depths / quantile_point_indices:
  * [num_rays][num_depth_quantiles] (NULL iff depth_quantiles NULL).  num_intersections may be
- * NULL.  point_contribution: [num_points] attr type, zero-filled by the caller, or NULL. */
+ * NULL.  point_contribution: [num_points] FLOAT32 for either attr type (accumulated with fp32
+ * atomics; the host mirror rounds to the attr type once), zero-filled by the caller, or NULL. */
 int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *settings,
                      uint32_t num_points, const float *points, const void *attributes,
                      uint32_t point_adjacency_size, const uint32_t *point_adjacency,
@@ -114,10 +119,11 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
                      const rf_launch_opts *opts, void *stream);
 
 /* Pipeline::trace_backward, src/tracing/pipeline.h:80-100 (kernel: pipeline.cu:132-343).
- * points_grad [num_points][3] f32, attribute_grad [num_points][A] attr type and point_error
- * [num_points] attr type (optional) must be zero-filled by the caller (the reference binding
- * does so, pipeline_bindings.cpp:441-452) and are accumulated into.  ray_grad is accepted for
- * signature parity and, as in the reference, never written. */
+ * points_grad [num_points][3], attribute_grad [num_points][A] and point_error [num_points]
+ * (optional) are FLOAT32 accumulators for either attr type (the host mirror rounds to the attr
+ * type once); they must be zero-filled by the caller (the reference binding does so,
+ * pipeline_bindings.cpp:441-452) and are accumulated into.  ray_grad is accepted for signature
+ * parity and, as in the reference, never written. */
 int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *settings,
                       uint32_t num_points, const float *points, const void *attributes,
                       uint32_t point_adjacency_size, const uint32_t *point_adjacency,
@@ -134,7 +140,8 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
  * camera is a HOST struct; start_point_index points at ONE device uint32; ray_rgba is
  * uint32[height*width], RGBA8 packed as make_rgba8 (tracing_utils.cuh:105-115).
  * The reference reads up to 3 table entries past the end of the last cell
- * (tracing_utils.cuh:43-50); this implementation never reads past point_adjacency_size. */
+ * (tracing_utils.cuh:43-50); this implementation never reads past point_adjacency_size: the
+ * table is copied entry by entry into the packed face table (cached via opts->foam_prepared). */
 int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *settings,
                        uint32_t num_points, const float *points, const void *attributes,
                        uint32_t point_adjacency_size, const uint32_t *point_adjacency,

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradfoam_hip.so")
+# RADFOAM_HIP_LIB selects another build of the same C-ABI (kernel A/B experiments)
+LIB_PATH = os.environ.get("RADFOAM_HIP_LIB") or os.path.join(_HERE, "libradfoam_hip.so")
 
 RF_OK = 0
 RF_ATTR_FLOAT32 = 0
@@ -61,7 +62,7 @@ SYMBOLS = {
     "rf_attribute_dim": (_U32, [_INT]),
     "rf_workspace_bytes": (C.c_size_t, [_U32, _U32, _INT, _INT]),
     "rf_build_adjacent_diff": (_INT, [_P, _U32, _U32, _P, _P, _P, _P]),
-    "rf_prepare_foam": (_INT, [_INT, _INT, _U32, _P, _P, _U32, _P, _P, _P, C.c_size_t, _P]),
+    "rf_prepare_foam": (_INT, [_INT, _INT, _U32, _P, _P, _U32, _P, _P, _P, _P, C.c_size_t, _P]),
     "rf_trace_forward": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _U32,
                                 _P, _P, _U32, _P, _P, _P, _P, _P, _P, C.POINTER(LaunchOpts), _P]),
     "rf_trace_backward": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _U32,

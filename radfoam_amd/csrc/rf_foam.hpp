@@ -1,21 +1,26 @@
 // rf_foam.hpp -- HBM layout of the packed foam the walk kernels read.
 //
 // The caller's tensors are AoS as the reference API dictates (points[N][3], attributes[N][A],
-// CSR offsets[N+1], adjacency[E]).  rf_prepare_foam re-lays the per-cell scalars the walk touches
-// on every step into one 32-byte record so that a hop costs two adjacent 16-byte gathers instead
-// of four scattered ones (offsets[i], offsets[i+1], points[i] (12 B, unaligned), density at the
-// end of the attribute row):
+// CSR offsets[N+1], adjacency[E]).  A hop of the reference walk chases four dependent pointers
+// (offsets[i], offsets[i+1] -> face table -> adjacency[e] -> points[j]); rf_prepare_foam re-lays
+// the foam so that a hop costs ONE dependent round trip:
 //
-//   workspace = [ RfCell cells[N] | half4 face_diff[E + 32] | SH rows[N][sh_stride] (optional) ]
+//   workspace = [ float4 cells[N] | uint4 faces[E + 32] | SH rows[N][sh_stride] (optional) ]
 //
-//   RfCell      {x, y, z, density, face_begin, face_end, 0, 0}            32 B, 32-B aligned
-//   face_diff   half4(points[adj[e]] - points[owner(e)], 0), RNE          8 B per CSR entry; the
-//               faces of one cell are one contiguous 8*F-byte run (reference layout,
-//               pipeline.cu:546-568, incl. its +32 entries of padding)
-//   SH rows     the 3B colour coefficients of a cell, 16-B aligned rows of sh_stride scalars;
-//               present only when the caller's row pitch (A scalars) is not 16-B aligned
-//               (fp32: d=1,3; fp16: all but d=3 use 8-B loads, d=1,3 are repacked); otherwise the
-//               kernels read the caller's attribute rows in place.
+//   cells[i]   {x, y, z, density}                                           16 B, 16-B aligned
+//   faces[e]   "fat" face entry, 16 B, one per CSR entry, a cell's faces contiguous:
+//                .x = half(dx) | half(dy) << 16      (dx,dy,dz) = points[adj[e]] - points[owner(e)],
+//                .y = half(dz) | nbr_faces << 16       fp16 RNE == the reference's half4 table
+//                .z = adj[e]                           (pipeline.cu:546-568)
+//                .w = offsets[adj[e]]                  the neighbour's first face
+//              so the winning face of a scan already names the next cell AND where its faces
+//              are: the next cell's face list, cell record and SH row can all be requested at once.
+//   SH rows    the 3B colour coefficients of a cell, 16-B aligned rows of sh_stride scalars;
+//              present only when the caller's row pitch (A scalars) is not 16-B aligned
+//              (d=1,3); otherwise the kernels read the caller's attribute rows in place.
+//
+// nbr_faces is 16 bits: cells with more than 65535 Delaunay neighbours are not supported
+// (rf_prepare_foam does not check; random and trained foams have < 100).
 #pragma once
 
 #include <stddef.h>
@@ -23,16 +28,11 @@
 
 namespace rf {
 
-struct alignas(32) RfCell {
-    float x, y, z, s;
-    uint32_t begin, end, pad0, pad1;
-};
-
-constexpr uint32_t kDiffPad = 32;  // entries; same slack the reference allocates (pipeline.cu:613)
+constexpr uint32_t kFacePad = 32;  // entries; same slack the reference allocates (pipeline.cu:613)
 
 struct FoamLayout {
     size_t cells_off;
-    size_t diff_off;
+    size_t faces_off;
     size_t sh_off;       // 0 when rows are read in place
     uint32_t sh_stride;  // scalars per SH row as the kernels see it
     bool sh_repacked;
@@ -55,9 +55,9 @@ inline FoamLayout foam_layout(uint32_t num_points, uint32_t adj_size, int sh_deg
     L.sh_repacked = !in_place;
     L.sh_stride = in_place ? A : (uint32_t)align_up(ncoef, 4);
     L.cells_off = 0;
-    size_t off = align_up((size_t)num_points * sizeof(RfCell), 256);
-    L.diff_off = off;
-    off = align_up(off + ((size_t)adj_size + kDiffPad) * 8, 256);
+    size_t off = align_up((size_t)num_points * 16, 256);
+    L.faces_off = off;
+    off = align_up(off + ((size_t)adj_size + kFacePad) * 16, 256);
     if (L.sh_repacked) {
         L.sh_off = off;
         off = align_up(off + (size_t)num_points * L.sh_stride * (attr_half ? 2 : 4), 256);

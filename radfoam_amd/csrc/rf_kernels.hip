@@ -1,13 +1,22 @@
 // rf_kernels.hip -- gfx950 (MI355X) kernels of the Voronoi-foam ray tracer + the C-ABI.
 //
-// One lane walks one ray.  A wave64 owns an 8x8 pixel tile when the rays form an image, so its
-// lanes sit in the same few cells: their face-table and cell-record gathers collapse to a
-// handful of cache lines, and face-count / step-count divergence inside the wave stays small.
+// One lane walks one ray; a wave64 owns an 8x8 pixel tile when the rays form an image, so its
+// lanes sit in the same few cells.  Per step the wave
+//   1. stages the face lists of its (up to kMaxDistinct) distinct current cells into LDS with
+//      one coalesced global->LDS DMA each (lanes in other cells fall back to their own loads),
+//   2. every lane scans its cell's faces out of LDS (broadcast reads) for the nearest exit,
+//   3. the winning "fat" face entry names the next cell AND its face range, so the next stage,
+//      the next cell record and the colour row are requested together: one dependent round
+//      trip per hop instead of the reference's four,
+//   4. composites the segment (forward) / accumulates gradients (backward) while those loads fly.
+// Backward pre-reduces gradient rows across the lanes that sit in the same cell with a
+// transposing DPP butterfly and issues ONE coalesced atomic row per distinct cell.
 // Blocks are handed to XCDs in contiguous chunks of the tile order so each XCD's private L2
 // sees one band of the image (= one slab of the foam).
 //
 // Kernels (reference counterparts in src/tracing/pipeline.cu):
-//   prepare_cells_kernel   prefetch_adjacent_diff_kernel :546-568  (+ cell-record packing)
+//   prepare_foam_kernel    prefetch_adjacent_diff_kernel :546-568  (+ cell/face packing)
+//   adjacent_diff_kernel   prefetch_adjacent_diff_kernel :546-568  (plain half4 table)
 //   repack_sh_kernel       (no counterpart: aligned SH rows)
 //   forward_kernel         forward :14-130 and benchmark :472-544
 //   backward_kernel        backward :132-343
@@ -20,6 +29,7 @@
 #include "../../include/radfoam_hip.h"
 #include "rf_foam.hpp"
 #include "rf_math.hpp"
+#include "rf_wave.hpp"
 
 namespace rf {
 
@@ -27,12 +37,11 @@ namespace rf {
 // views and parameters
 
 struct FoamView {
-    const RfCell *cells;
-    const uint2 *diff;      // half4 entries (8 B)
-    const uint32_t *adj;
-    const void *sh;         // SH rows, sh_stride scalars apart
+    const float4 *cells;        // {x, y, z, density}
+    const uint4 *faces;         // fat face entries (rf_foam.hpp)
+    const uint32_t *offsets;    // caller's CSR offsets (entry cell's face range)
+    const void *sh;             // SH rows, sh_stride scalars apart
     uint32_t sh_stride;
-    uint32_t diff_count;    // readable entries (only used by CLAMP instances)
 };
 
 struct RayGrid {
@@ -76,8 +85,18 @@ struct BwdParams {
     float *points_grad;
     float *attr_grad;   // fp32 accumulator [N][A]
     float *point_error; // fp32 accumulator [N]
-    uint32_t attr_dim;
 };
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+#ifndef RF_MAX_DISTINCT
+#define RF_MAX_DISTINCT 4
+#endif
+#ifndef RF_STAGE_CAP
+#define RF_STAGE_CAP 160
+#endif
+constexpr int kMaxDistinct = RF_MAX_DISTINCT;  // distinct cells per wave-step staged through LDS
+constexpr int kStageCap = RF_STAGE_CAP;        // fat entries of LDS per wave (16 B each)
 
 // ------------------------------------------------------------------------------------------
 // block -> tile, lane -> ray
@@ -102,83 +121,125 @@ __device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray) {
         ray = y * g.img_w + x;
         return x < g.img_w && y < g.img_h;
     }
-    ray = blk * 256u + tid;
+    ray = blk * (uint32_t)kBlock + tid;
     return ray < g.num_rays;
 }
 
 inline uint32_t grid_blocks(const RayGrid &g) {
     if (g.img_w) return ((g.img_w + 15u) >> 4) * ((g.img_h + 15u) >> 4);
-    return (g.num_rays + 255u) / 256u;
+    return (g.num_rays + (uint32_t)kBlock - 1u) / (uint32_t)kBlock;
 }
 
+// ------------------------------------------------------------------------------------------
+// staging of face lists: global -> LDS, one DMA per distinct cell of the wave
 
-// One packed cell record, fetched as two naturally aligned 16-byte loads.
-struct CellRec {
-    float x, y, z, s;
-    uint32_t begin, end;
-};
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
 
-__device__ __forceinline__ CellRec load_cell(const RfCell *cells, uint32_t i) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(cells) + 2 * (size_t)i;
-    uint4 a = q[0];
-    uint4 b = q[1];
-    CellRec c;
-    c.x = bits2f(a.x);
-    c.y = bits2f(a.y);
-    c.z = bits2f(a.z);
-    c.s = bits2f(a.w);
-    c.begin = b.x;
-    c.end = b.y;
-    return c;
+// Every lane calls this (convergent).  `need` lanes want faces [nb, nb+cnt) of the fat table.
+// Returns the lane's entry offset into `lds`, or kNone if its cell was not staged (more than
+// kMaxDistinct distinct cells in the wave, a list longer than 64, or LDS space exhausted): such
+// lanes read the table from global memory instead.  The DMA is asynchronous: the caller must
+// execute wait_staged() before reading `lds`.
+__device__ __forceinline__ uint32_t stage_faces(const uint4 *faces, uint4 *lds, uint32_t lane,
+                                                bool need, uint32_t nb, uint32_t cnt) {
+    uint32_t my = kNone;
+    uint32_t used = 0;
+    uint64_t todo = ballot(need);
+#pragma unroll
+    for (int it = 0; it < kMaxDistinct; ++it) {
+        if (todo != 0ull) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t b = readlane(nb, leader);
+            const uint32_t c = readlane(cnt, leader);
+            const bool mine = need && nb == b;
+            const uint64_t same = ballot(mine);
+            if (c <= 64u && used + c <= (uint32_t)kStageCap) {
+                if (lane < c) {
+                    // lane l copies entry b+l to lds[used + l]  (LDS address = M0 base + 16*lane)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(faces + b + lane), (lptr_t)(lds + used), 16, 0, 0);
+                }
+                if (mine) my = used;
+                used += c;
+            }
+            todo &= ~same;
+        }
+    }
+    return my;
 }
+
+__device__ __forceinline__ void wait_staged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------
 // the per-cell face scan                         reference: trace<>, tracing_utils.cuh:27-67
 
-struct __attribute__((aligned(8))) FacePair {
-    uint32_t a0, a1, b0, b1;
+struct ScanResult {
+    float t1;
+    uint32_t k;     // winning face, relative to the cell's first face; kNone if no exit
+    uint32_t w1;    // second dword of the winning entry (neighbour's face count in the high half)
 };
 
-// Nearest exit of the ray from the cell whose faces are entries [b,e) of the face table.
-// Ascending order with a strict '<' (first minimum wins), like the reference.
-template <bool CLAMP>
-__device__ __forceinline__ void scan_cell(const FoamView &fv, uint32_t b, uint32_t e, float Px,
-                                          float Py, float Pz, float Ox, float Oy, float Oz,
-                                          float dx, float dy, float dz, float &t1, uint32_t &best) {
-    t1 = __builtin_inff();
-    best = kNone;
-    for (uint32_t f = b; f < e; f += 2) {
-        FacePair fp;
-        if constexpr (CLAMP) {
-            // caller-owned table without padding: never read entry diff_count
-            uint32_t fc = (f + 1 < fv.diff_count) ? f : fv.diff_count - 2;
-            fp = *reinterpret_cast<const FacePair *>(fv.diff + fc);
-            if (fc != f) {
-                fp.a0 = fp.b0;
-                fp.a1 = fp.b1;
-            }
-        } else {
-            fp = *reinterpret_cast<const FacePair *>(fv.diff + f);
+// t of the ray/bisector hit for one face; dp > 0 <=> the ray leaves through it
+__device__ __forceinline__ void face_hit(uint2 e, float Px, float Py, float Pz, float Ox, float Oy,
+                                         float Oz, float dx, float dy, float dz, float &dp, float &t) {
+    float ox = half_lo(e.x), oy = half_hi(e.x), oz = half_lo(e.y);
+    dp = dot3(ox, oy, oz, dx, dy, dz);
+    float vx = fma_(ox, 0.5f, Px) - Ox;
+    float vy = fma_(oy, 0.5f, Py) - Oy;
+    float vz = fma_(oz, 0.5f, Pz) - Oz;
+    t = dot3(vx, vy, vz, ox, oy, oz) / dp;
+}
+
+// Nearest exit of the ray from the cell whose faces are fat entries [nb, nb+cnt); ascending
+// order, strict '<' (the first minimum wins, like the reference).  `my` != kNone: the list was
+// staged at lds[my..]; else it is read from global memory.  Four faces per iteration are
+// evaluated branch-free as independent chains (ILP; the IEEE divide is an 11-instruction
+// dependent sequence), the next four are fetched meanwhile.  Reads may run up to 7 entries
+// past the list: both the LDS stage and the table are padded.
+template <bool FROM_LDS>
+__device__ __forceinline__ ScanResult scan_faces(const uint4 *src, uint32_t cnt, float Px, float Py,
+                                                 float Pz, float Ox, float Oy, float Oz, float dx,
+                                                 float dy, float dz) {
+    ScanResult r;
+    r.t1 = __builtin_inff();
+    r.k = kNone;
+    r.w1 = 0u;
+    uint2 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = *reinterpret_cast<const uint2 *>(src + j);
+    for (uint32_t k = 0; k < cnt; k += 4) {
+        uint2 nx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nx[j] = *reinterpret_cast<const uint2 *>(src + k + 4 + j);
+        float dp[4], t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) face_hit(e[j], Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz, dp[j], t[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool better = (dp[j] > 0.0f) && (k + j < cnt) && (t[j] < r.t1);
+            r.t1 = better ? t[j] : r.t1;
+            r.k = better ? k + j : r.k;
+            r.w1 = better ? e[j].y : r.w1;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            uint32_t w0 = j ? fp.b0 : fp.a0, w1 = j ? fp.b1 : fp.a1;
-            float ox = half_lo(w0), oy = half_hi(w0), oz = half_lo(w1);
-            float dp = dot3(ox, oy, oz, dx, dy, dz);
-            bool cand = (dp > 0.0f) && (f + j < e);
-            // wave-uniform skip: back-facing planes need neither the numerator nor the divide
-            if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
-                float vx = fma_(ox, 0.5f, Px) - Ox;
-                float vy = fma_(oy, 0.5f, Py) - Oy;
-                float vz = fma_(oz, 0.5f, Pz) - Oz;
-                float t = dot3(vx, vy, vz, ox, oy, oz) / dp;
-                if (cand && t < t1) {
-                    t1 = t;
-                    best = f + j;
-                }
-            }
-        }
+        for (int j = 0; j < 4; ++j) e[j] = nx[j];
     }
+    return r;
+}
+
+__device__ __forceinline__ ScanResult scan_cell(const uint4 *faces, const uint4 *lds, uint32_t my,
+                                                uint32_t nb, uint32_t cnt, float Px, float Py,
+                                                float Pz, float Ox, float Oy, float Oz, float dx,
+                                                float dy, float dz) {
+    if (my != kNone) return scan_faces<true>(lds + my, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
+    return scan_faces<false>(faces + nb, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
+}
+
+// {neighbour index, neighbour's first face} of entry k
+__device__ __forceinline__ uint2 face_link(const uint4 *faces, const uint4 *lds, uint32_t my,
+                                           uint32_t nb, uint32_t k) {
+    if (my != kNone) return *(reinterpret_cast<const uint2 *>(lds + my + k) + 1);
+    return *(reinterpret_cast<const uint2 *>(faces + nb + k) + 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -281,10 +342,15 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 // Control flow: every lane keeps an `alive` flag and the wave iterates while any lane is alive
 // (no per-lane `break` out of nested conditionals).  hipcc 7.2 was observed to miscompile the
 // natural `for(;;){...break...}` form of this loop (the next cell's face range was dropped on
-// the path through the compositing block); the flag form also is what lane compaction needs.
+// the path through the compositing block); the flag form is also what wave-cooperative
+// staging needs (all lanes must reach stage_faces together).
 
 template <int DEG, bool HALF, bool BENCH>
-__global__ __launch_bounds__(256) void forward_kernel(FwdParams p) {
+__global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
+    __shared__ uint4 s_faces[kWaves * kStageCap + 8];
+    uint4 *lds = s_faces + (threadIdx.x >> 6) * kStageCap;
+    const uint32_t lane = threadIdx.x & 63u;
+
     uint32_t ray;
     bool alive = map_ray(p.grid, ray);
     const FoamView &fv = p.foam;
@@ -334,33 +400,58 @@ __global__ __launch_bounds__(256) void forward_kernel(FwdParams p) {
     const float thr = p.settings.weight_threshold;
     const uint32_t max_steps = p.settings.max_intersections;
 
-    unsigned long long st_cells = 0, st_faces = 0, st_hops = 0, st_seg = 0, st_lit = 0;
+    unsigned long long st_cells = 0, st_faces = 0, st_hops = 0, st_seg = 0, st_lit = 0, st_staged = 0;
     const bool want_stats = !BENCH && p.stats != nullptr;
 
     float t0 = 0.0f;
     uint32_t n = 0;
-    CellRec head = load_cell(fv.cells, cur);
-    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+    uint32_t nb = 0, cnt = 0;
+    float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (alive) {
+        nb = fv.offsets[cur];
+        cnt = fv.offsets[cur + 1] - nb;
+        head = fv.cells[cur];
+    }
+    uint32_t my = stage_faces(fv.faces, lds, lane, alive, nb, cnt);
+
+    uint32_t wave_steps = 0;
+    while (ballot(alive) != 0ull) {
+        wave_steps++;
         if (alive) {
             n++;
             if (n > max_steps) alive = false;
         }
-        float t1 = __builtin_inff();
-        uint32_t best = kNone;
+        wait_staged();
+        ScanResult sr;
+        sr.t1 = __builtin_inff();
+        sr.k = kNone;
+        sr.w1 = 0u;
         if (alive) {
-            scan_cell<BENCH>(fv, head.begin, head.end, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, t1, best);
+            sr = scan_cell(fv.faces, lds, my, nb, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
             if (want_stats) {
                 st_cells++;
-                st_faces += head.end - head.begin;
+                st_faces += cnt;
+                st_staged += (my != kNone) ? 1u : 0u;
             }
-            if (best == kNone) alive = false;
+            if (sr.k == kNone) alive = false;
         }
+        uint32_t nxt = 0, nnb = 0, ncnt = 0;
+        float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (alive) {
-            const uint32_t nxt = fv.adj[best];
-            const CellRec nhead = load_cell(fv.cells, nxt);
+            uint2 link = face_link(fv.faces, lds, my, nb, sr.k);
+            nxt = link.x;
+            nnb = link.y;
+            ncnt = sr.w1 >> 16;
+            nhead = fv.cells[nxt];
+        }
+        // every LDS read of this step has been consumed: re-stage for the next step now, so the
+        // DMA flies while the segment is composited
+        const uint32_t nmy = stage_faces(fv.faces, lds, lane, alive, nnb, ncnt);
+        if (alive) {
+            const float t1 = sr.t1;
             if (want_stats) st_hops++;
             if (t1 > t0) {
-                float s = head.s;
+                float s = head.w;
                 float r = 0.0f, g = 0.0f, b = 0.0f;
                 if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
                 if (want_stats) {
@@ -391,8 +482,12 @@ __global__ __launch_bounds__(256) void forward_kernel(FwdParams p) {
             t0 = __builtin_fmaxf(t0, t1);
             cur = nxt;
             head = nhead;
+            nb = nnb;
+            cnt = ncnt;
+            my = nmy;
         }
     }
+    wait_staged();  // no DMA may be in flight into this wave's LDS when the block retires
 
     if (!valid) return;
     if constexpr (BENCH) {
@@ -418,6 +513,8 @@ __global__ __launch_bounds__(256) void forward_kernel(FwdParams p) {
             atomicAdd(p.stats + 2, st_hops);
             atomicAdd(p.stats + 3, st_seg);
             atomicAdd(p.stats + 4, st_lit);
+            atomicAdd(p.stats + 5, st_staged);
+            if (lane == 0) atomicAdd(p.stats + 6, (unsigned long long)wave_steps);
         }
     }
 }
@@ -428,7 +525,10 @@ __global__ __launch_bounds__(256) void forward_kernel(FwdParams p) {
 // reference's behaviours are kept: the accumulators of the last visited
 // cell and of its exit neighbour are never flushed; the first segment's dt0/dP term is taken
 // against the world origin; dL/dt0 receives depth_grad/s.
+//
 // MODE 1: one atomic per lane per value (the reference's scatter).
+// MODE 2: lanes of the wave that sit in the same cell first sum their rows with a transposing
+//         butterfly (rf_wave.hpp); one coalesced atomic row per distinct cell.
 
 template <bool HALF>
 __device__ __forceinline__ float load_attr_scalar(const void *base, size_t i) {
@@ -439,13 +539,118 @@ __device__ __forceinline__ float load_attr_scalar(const void *base, size_t i) {
     }
 }
 
-template <int DEG, bool HALF>
-__global__ __launch_bounds__(256) void backward_kernel(BwdParams p) {
+constexpr int pow2_at_least(int v) { return v <= 8 ? 8 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
+
+template <int NB>
+__device__ __forceinline__ void add_row_per_lane(float *dst, const float (&sh)[NB], float dLr,
+                                                 float dLg, float dLb) {
+#pragma unroll
+    for (int i = 0; i < 3 * NB; ++i) {
+        float gc = (i % 3 == 0) ? dLr : ((i % 3 == 1) ? dLg : dLb);
+        unsafeAtomicAdd(dst + i, sh[i / 3] * gc);
+    }
+}
+
+// Adds this step's gradients to global memory.  Called by every lane (convergent).
+//   has      lane composited a segment this step
+//   row      its colour-gradient row is not all zero (lit cell, unclamped channel)
+//   cur      the cell the row / density gradient belongs to
+//   pg_on    (pgx,pgy,pgz) must be added to points_grad[prev]
+template <int DEG, int MODE>
+__device__ __forceinline__ void scatter_step(uint32_t lane, bool has, bool row, uint32_t cur,
+                                             const float (&sh)[sh_dim(DEG)], float dLr, float dLg,
+                                             float dLb, float dL_ds, bool pg_on, uint32_t prev,
+                                             float pgx, float pgy, float pgz, float *attr_grad,
+                                             float *points_grad) {
+    constexpr int NB = sh_dim(DEG);
+    constexpr int A = 1 + 3 * NB;
+    if constexpr (MODE == 1) {
+        if (has) {
+            if (pg_on) {
+                float *pg = points_grad + 3 * (size_t)prev;
+                unsafeAtomicAdd(pg + 0, pgx);
+                unsafeAtomicAdd(pg + 1, pgy);
+                unsafeAtomicAdd(pg + 2, pgz);
+            }
+            float *dst = attr_grad + (size_t)cur * A;
+            if (row) add_row_per_lane<NB>(dst, sh, dLr, dLg, dLb);
+            unsafeAtomicAdd(dst + (A - 1), dL_ds);
+        }
+    } else {
+        constexpr int NV = pow2_at_least(A + 3);   // row (A values) + point gradient (3)
+        bool pg_left = has && pg_on;        // point gradient not yet added
+        bool ds_left = has;                 // density gradient not yet added
+        // ---- full rows, one butterfly per distinct cell
+        uint64_t todo = ballot(has && row);
+        while (todo != 0ull) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t c = readlane(cur, leader);
+            const bool mine = has && row && cur == c;
+            const uint64_t same = ballot(mine);
+            if (__builtin_popcountll(same) <= 2) {
+                // (almost) nothing to share: the lanes add their own rows
+                if (mine) add_row_per_lane<NB>(attr_grad + (size_t)cur * A, sh, dLr, dLg, dLb);
+            } else {
+                // the point gradient rides along when the whole group flushes to the same cell
+                const uint32_t pl = readlane(prev, leader);
+                const bool pg_uniform = ballot(mine && pg_on && prev != pl) == 0ull;
+                const bool take_pg = mine && pg_on && pg_uniform;
+                const bool any_pg = ballot(take_pg) != 0ull;
+                float v[NV];
+                const float mr = mine ? dLr : 0.0f, mg = mine ? dLg : 0.0f, mb = mine ? dLb : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 3 * NB; ++i) {
+                    float gc = (i % 3 == 0) ? mr : ((i % 3 == 1) ? mg : mb);
+                    v[i] = sh[i / 3] * gc;
+                }
+                v[A - 1] = mine ? dL_ds : 0.0f;
+                v[A + 0] = take_pg ? pgx : 0.0f;
+                v[A + 1] = take_pg ? pgy : 0.0f;
+                v[A + 2] = take_pg ? pgz : 0.0f;
+#pragma unroll
+                for (int i = A + 3; i < NV; ++i) v[i] = 0.0f;
+                const float tot = transpose_reduce<NV>(v, lane);
+                if (lane < (uint32_t)A) {
+                    unsafeAtomicAdd(attr_grad + (size_t)c * A + lane, tot);
+                } else if (lane < (uint32_t)(A + 3) && any_pg) {
+                    unsafeAtomicAdd(points_grad + 3 * (size_t)pl + (lane - (uint32_t)A), tot);
+                }
+                if (mine) ds_left = false;
+                if (take_pg) pg_left = false;
+            }
+            todo &= ~same;
+        }
+        // ---- density gradient of lanes whose row was not reduced above, per distinct cell
+        todo = ballot(ds_left);
+        while (todo != 0ull) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t c = readlane(cur, leader);
+            const bool mine = ds_left && cur == c;
+            const uint64_t same = ballot(mine);
+            const float tot = wave_sum(mine ? dL_ds : 0.0f);
+            if ((int)lane == leader) unsafeAtomicAdd(attr_grad + (size_t)c * A + (A - 1), tot);
+            todo &= ~same;
+        }
+        // ---- point gradients that did not ride along
+        if (pg_left) {
+            float *pg = points_grad + 3 * (size_t)prev;
+            unsafeAtomicAdd(pg + 0, pgx);
+            unsafeAtomicAdd(pg + 1, pgy);
+            unsafeAtomicAdd(pg + 2, pgz);
+        }
+    }
+}
+
+template <int DEG, bool HALF, int MODE>
+__global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
+    __shared__ uint4 s_faces[kWaves * kStageCap + 8];
+    uint4 *lds = s_faces + (threadIdx.x >> 6) * kStageCap;
+    const uint32_t lane = threadIdx.x & 63u;
+
     uint32_t ray;
     bool alive = map_ray(p.grid, ray);
     const FoamView &fv = p.foam;
     constexpr int NB = sh_dim(DEG);
-    constexpr int A = 1 + 3 * NB;
 
     float Ox = 0.0f, Oy = 0.0f, Oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 1.0f;
     float gr = 0.0f, gg = 0.0f, gb = 0.0f, ga = 0.0f, outr = 0.0f, outg = 0.0f, outb = 0.0f, outa = 0.0f;
@@ -485,7 +690,7 @@ __global__ __launch_bounds__(256) void backward_kernel(BwdParams p) {
             for (uint32_t i = 0; i < nq; ++i) {
                 uint32_t ci = p.qidx[(size_t)ray * nq + i];
                 if (ci != kNone) {
-                    float s = load_cell(fv.cells, ci).s;
+                    float s = fv.cells[ci].w;
                     cdg += dgp[i] / s;
                 }
             }
@@ -505,23 +710,59 @@ __global__ __launch_bounds__(256) void backward_kernel(BwdParams p) {
 
     float t0 = 0.0f;
     uint32_t n = 0;
-    CellRec head = load_cell(fv.cells, cur);
-    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+    uint32_t nb = 0, cnt = 0;
+    float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (alive) {
+        nb = fv.offsets[cur];
+        cnt = fv.offsets[cur + 1] - nb;
+        head = fv.cells[cur];
+    }
+    uint32_t my = stage_faces(fv.faces, lds, lane, alive, nb, cnt);
+
+    // Gradient contributions of the step just finished.  They are scattered at the top of the
+    // NEXT iteration, right after the wait for the staged faces: the atomics then complete
+    // under the long face scan instead of sitting in front of the next wait (memory operations
+    // retire in order, so an atomic issued after the stage DMA would otherwise delay it).
+    bool has = false, row = false, pg_on = false;
+    uint32_t s_cur = 0, s_prev = kNone;
+    float dLr = 0.0f, dLg = 0.0f, dLb = 0.0f, dL_ds = 0.0f, fpx = 0.0f, fpy = 0.0f, fpz = 0.0f;
+
+    while (ballot(alive) != 0ull) {
         if (alive) {
             n++;
             if (n > max_steps) alive = false;
         }
-        float t1 = __builtin_inff();
-        uint32_t best = kNone;
-        if (alive) {
-            scan_cell<false>(fv, head.begin, head.end, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, t1, best);
-            if (best == kNone) alive = false;
+        wait_staged();
+        if (ballot(has) != 0ull) {
+            scatter_step<DEG, MODE>(lane, has, row, s_cur, sh, dLr, dLg, dLb, dL_ds, pg_on, s_prev, fpx, fpy,
+                                    fpz, p.attr_grad, p.points_grad);
         }
+        has = false;
+        row = false;
+        pg_on = false;
+        ScanResult sr;
+        sr.t1 = __builtin_inff();
+        sr.k = kNone;
+        sr.w1 = 0u;
         if (alive) {
-            const uint32_t nxt = fv.adj[best];
-            const CellRec nhead = load_cell(fv.cells, nxt);
+            sr = scan_cell(fv.faces, lds, my, nb, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
+            if (sr.k == kNone) alive = false;
+        }
+        uint32_t nxt = 0, nnb = 0, ncnt = 0;
+        float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (alive) {
+            uint2 link = face_link(fv.faces, lds, my, nb, sr.k);
+            nxt = link.x;
+            nnb = link.y;
+            ncnt = sr.w1 >> 16;
+            nhead = fv.cells[nxt];
+        }
+        const uint32_t nmy = stage_faces(fv.faces, lds, lane, alive, nnb, ncnt);
+
+        if (alive) {
+            const float t1 = sr.t1;
             if (t1 > t0) {
-                float s = head.s;
+                float s = head.w;
                 float r = 0.0f, g = 0.0f, b = 0.0f;
                 if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
                 float dt = __builtin_fmaxf(t1 - t0, 0.0f);
@@ -535,7 +776,9 @@ __global__ __launch_bounds__(256) void backward_kernel(BwdParams p) {
                 Cb = fma_(w, b, Cb);
                 if (p.point_error) unsafeAtomicAdd(p.point_error + cur, w * err);
 
-                float dLr = gr * w, dLg = gg * w, dLb = gb * w;
+                dLr = gr * w;
+                dLg = gg * w;
+                dLb = gb * w;
                 float den = T * ((1.0f - alpha) + 1e-6f);
                 float dfr = r - (outr - Cr) / den;
                 float dfg = g - (outg - Cg) / den;
@@ -543,7 +786,7 @@ __global__ __launch_bounds__(256) void backward_kernel(BwdParams p) {
                 float dL_da = T * dot3(dfr, dfg, dfb, gr, gg, gb);
                 dL_da = dL_da + ((1.0f - outa) * ga) / ((1.0f - alpha) + 1e-6f);
 
-                float dL_ds = dL_da * da_ds;
+                dL_ds = dL_da * da_ds;
                 float dL_ddt = dL_da * da_ddt;
                 float dL_dt0 = 0.0f;
 
@@ -583,12 +826,21 @@ __global__ __launch_bounds__(256) void backward_kernel(BwdParams p) {
                 ngy = fma_(dL_dt1, fy, ngy);
                 ngz = fma_(dL_dt1, fz, ngz);
 
-                if (prev != kNone) {
-                    float *pg = p.points_grad + 3 * (size_t)prev;
-                    unsafeAtomicAdd(pg + 0, pgx);
-                    unsafeAtomicAdd(pg + 1, pgy);
-                    unsafeAtomicAdd(pg + 2, pgz);
-                }
+                // what the reference adds with atomics at this point (pipeline.cu:305-328):
+                // prev_point_grad -> points_grad[prev]; the SH row and dL/ds -> attr_grad[cur].
+                // Exact zeros are not added (adding +0 changes nothing).
+                has = true;
+                s_cur = cur;
+                s_prev = prev;
+                fpx = pgx;
+                fpy = pgy;
+                fpz = pgz;
+                pg_on = (prev != kNone) && (pgx != 0.0f || pgy != 0.0f || pgz != 0.0f);
+                if (r == 0.0f) dLr = 0.0f;
+                if (g == 0.0f) dLg = 0.0f;
+                if (b == 0.0f) dLb = 0.0f;
+                row = (dLr != 0.0f || dLg != 0.0f || dLb != 0.0f);
+
                 ppx = head.x;
                 ppy = head.y;
                 ppz = head.z;
@@ -601,56 +853,73 @@ __global__ __launch_bounds__(256) void backward_kernel(BwdParams p) {
                 cgz = ngz;
                 ngx = ngy = ngz = 0.0f;
                 T = Tn;
-
-                if (r == 0.0f) dLr = 0.0f;
-                if (g == 0.0f) dLg = 0.0f;
-                if (b == 0.0f) dLb = 0.0f;
-                float *row = p.attr_grad + (size_t)cur * A;
-                // all-zero colour gradients (empty cells, clamped channels) add nothing: skip them
-                if (dLr != 0.0f || dLg != 0.0f || dLb != 0.0f) {
-#pragma unroll
-                    for (int i = 0; i < 3 * NB; ++i) {
-                        float gc = (i % 3 == 0) ? dLr : ((i % 3 == 1) ? dLg : dLb);
-                        unsafeAtomicAdd(row + i, sh[i / 3] * gc);
-                    }
-                }
-                unsafeAtomicAdd(row + (A - 1), dL_ds);
-
                 if (!(T > thr)) alive = false;
             }
             t0 = __builtin_fmaxf(t0, t1);
             cur = nxt;
             head = nhead;
+            nb = nnb;
+            cnt = ncnt;
+            my = nmy;
         }
+    }
+    wait_staged();
+    if (ballot(has) != 0ull) {
+        scatter_step<DEG, MODE>(lane, has, row, s_cur, sh, dLr, dLg, dLb, dL_ds, pg_on, s_prev, fpx, fpy, fpz,
+                                p.attr_grad, p.points_grad);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // foam packing
 
+__device__ __forceinline__ uint2 pack_diff(float dx, float dy, float dz) {
+    uint32_t lo = (uint32_t)float_to_half_bits(dx) | ((uint32_t)float_to_half_bits(dy) << 16);
+    uint32_t hi = (uint32_t)float_to_half_bits(dz);
+    return make_uint2(lo, hi);
+}
+
+// cells[i] = {x,y,z,density}; faces[e] = fat entry (rf_foam.hpp).  ext_diff != nullptr: take the
+// half offsets from the caller's half4 table instead of recomputing them (trace_benchmark).
 template <bool HALF>
-__global__ __launch_bounds__(256) void prepare_cells_kernel(
+__global__ __launch_bounds__(256) void prepare_foam_kernel(
     const float *__restrict__ points, const void *__restrict__ attributes, uint32_t attr_dim,
     uint32_t num_points, const uint32_t *__restrict__ adj, const uint32_t *__restrict__ offsets,
-    RfCell *__restrict__ cells, uint2 *__restrict__ diff, int write_cells, int write_diff) {
+    const uint2 *__restrict__ ext_diff, float4 *__restrict__ cells, uint4 *__restrict__ faces) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_points) return;
     float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
     uint32_t b = offsets[i], e = offsets[i + 1];
-    if (write_cells) {
-        float s = load_attr_scalar<HALF>(attributes, (size_t)i * attr_dim + attr_dim - 1);
-        float4 *c4 = reinterpret_cast<float4 *>(cells + i);
-        c4[0] = make_float4(px, py, pz, s);
-        reinterpret_cast<uint4 *>(c4)[1] = make_uint4(b, e, 0u, 0u);
-    }
-    if (write_diff) {
-        for (uint32_t f = b; f < e; ++f) {
-            uint32_t q = adj[f];
+    float s = load_attr_scalar<HALF>(attributes, (size_t)i * attr_dim + attr_dim - 1);
+    cells[i] = make_float4(px, py, pz, s);
+    for (uint32_t f = b; f < e; ++f) {
+        uint32_t q = adj[f];
+        uint2 d;
+        if (ext_diff) {
+            d = ext_diff[f];
+            d.y &= 0xFFFFu;
+        } else {
             float qx = points[3 * (size_t)q], qy = points[3 * (size_t)q + 1], qz = points[3 * (size_t)q + 2];
-            uint32_t lo = (uint32_t)float_to_half_bits(qx - px) | ((uint32_t)float_to_half_bits(qy - py) << 16);
-            uint32_t hi = (uint32_t)float_to_half_bits(qz - pz);
-            diff[f] = make_uint2(lo, hi);
+            d = pack_diff(qx - px, qy - py, qz - pz);
         }
+        uint32_t qb = offsets[q], qe = offsets[q + 1];
+        faces[f] = make_uint4(d.x, d.y | ((qe - qb) << 16), q, qb);
+    }
+}
+
+// plain half4 table of the reference (pipeline.cu:546-568)
+__global__ __launch_bounds__(256) void adjacent_diff_kernel(const float *__restrict__ points,
+                                                            uint32_t num_points,
+                                                            const uint32_t *__restrict__ adj,
+                                                            const uint32_t *__restrict__ offsets,
+                                                            uint2 *__restrict__ diff) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_points) return;
+    float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
+    for (uint32_t f = offsets[i]; f < offsets[i + 1]; ++f) {
+        uint32_t q = adj[f];
+        diff[f] = pack_diff(points[3 * (size_t)q] - px, points[3 * (size_t)q + 1] - py,
+                            points[3 * (size_t)q + 2] - pz);
     }
 }
 
@@ -689,42 +958,38 @@ static bool valid_instance(int sh_degree, int attr_type) {
     return sh_degree >= 0 && sh_degree <= 3 && (attr_type == RF_ATTR_FLOAT32 || attr_type == RF_ATTR_FLOAT16);
 }
 
-static FoamView make_view(const FoamLayout &L, void *ws, const void *attributes, const uint32_t *adj,
-                          uint32_t adj_size) {
+static FoamView make_view(const FoamLayout &L, void *ws, const void *attributes, const uint32_t *offsets) {
     FoamView v;
     char *base = static_cast<char *>(ws);
-    v.cells = reinterpret_cast<const RfCell *>(base + L.cells_off);
-    v.diff = reinterpret_cast<const uint2 *>(base + L.diff_off);
-    v.adj = adj;
+    v.cells = reinterpret_cast<const float4 *>(base + L.cells_off);
+    v.faces = reinterpret_cast<const uint4 *>(base + L.faces_off);
+    v.offsets = offsets;
     v.sh = L.sh_repacked ? static_cast<const void *>(base + L.sh_off) : attributes;
     v.sh_stride = L.sh_stride;
-    v.diff_count = adj_size + kDiffPad;
     return v;
 }
 
 static int prepare_impl(int sh_degree, int attr_type, uint32_t num_points, const float *points,
                         const void *attributes, uint32_t adj_size, const uint32_t *adj,
-                        const uint32_t *offsets, void *ws, size_t ws_bytes, bool write_diff,
+                        const uint32_t *offsets, const void *ext_diff, void *ws, size_t ws_bytes,
                         hipStream_t stream) {
     const bool half = attr_type == RF_ATTR_FLOAT16;
     FoamLayout L = foam_layout(num_points, adj_size, sh_degree, half);
     if (!ws || ws_bytes < L.total) return fail(RF_ERR_WORKSPACE, "workspace missing or smaller than rf_workspace_bytes()");
     if (num_points == 0) return RF_OK;
     char *base = static_cast<char *>(ws);
-    RfCell *cells = reinterpret_cast<RfCell *>(base + L.cells_off);
-    uint2 *diff = reinterpret_cast<uint2 *>(base + L.diff_off);
+    float4 *cells = reinterpret_cast<float4 *>(base + L.cells_off);
+    uint4 *faces = reinterpret_cast<uint4 *>(base + L.faces_off);
     const uint32_t A = attribute_dim(sh_degree);
     dim3 grid((num_points + 255u) / 256u), block(256);
     if (half)
-        hipLaunchKernelGGL(prepare_cells_kernel<true>, grid, block, 0, stream, points, attributes, A,
-                           num_points, adj, offsets, cells, diff, 1, write_diff ? 1 : 0);
+        hipLaunchKernelGGL(prepare_foam_kernel<true>, grid, block, 0, stream, points, attributes, A, num_points,
+                           adj, offsets, static_cast<const uint2 *>(ext_diff), cells, faces);
     else
-        hipLaunchKernelGGL(prepare_cells_kernel<false>, grid, block, 0, stream, points, attributes, A,
-                           num_points, adj, offsets, cells, diff, 1, write_diff ? 1 : 0);
-    if (write_diff) {
-        // zero the padding so over-reads past the last cell see finite values
-        hipMemsetAsync(diff + adj_size, 0, (size_t)kDiffPad * 8, stream);
-    }
+        hipLaunchKernelGGL(prepare_foam_kernel<false>, grid, block, 0, stream, points, attributes, A, num_points,
+                           adj, offsets, static_cast<const uint2 *>(ext_diff), cells, faces);
+    // zero the padding so over-reads past the last cell see well-defined (never selected) entries
+    (void)hipMemsetAsync(faces + adj_size, 0, (size_t)kFacePad * 16, stream);
     if (L.sh_repacked) {
         size_t total = (size_t)num_points * L.sh_stride;
         dim3 g2((unsigned)((total + 255) / 256));
@@ -760,19 +1025,22 @@ struct LaunchForward {
         uint32_t nb = grid_blocks(p.grid);
         if (nb == 0) return RF_OK;
         if (bench)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, true>), dim3(nb), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, true>), dim3(nb), dim3(kBlock), 0, stream, p);
         else
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false>), dim3(nb), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false>), dim3(nb), dim3(kBlock), 0, stream, p);
         return check_launch(bench ? "rf_trace_benchmark" : "rf_trace_forward");
     }
 };
 
 template <int DEG, bool HALF>
 struct LaunchBackward {
-    static int run(const BwdParams &p, hipStream_t stream) {
+    static int run(const BwdParams &p, int mode, hipStream_t stream) {
         uint32_t nb = grid_blocks(p.grid);
         if (nb == 0) return RF_OK;
-        hipLaunchKernelGGL((backward_kernel<DEG, HALF>), dim3(nb), dim3(256), 0, stream, p);
+        if (mode == 1)
+            hipLaunchKernelGGL((backward_kernel<DEG, HALF, 1>), dim3(nb), dim3(kBlock), 0, stream, p);
+        else
+            hipLaunchKernelGGL((backward_kernel<DEG, HALF, 2>), dim3(nb), dim3(kBlock), 0, stream, p);
         return check_launch("rf_trace_backward");
     }
 };
@@ -814,25 +1082,24 @@ int rf_build_adjacent_diff(const float *points, uint32_t num_points, uint32_t po
     if (num_points == 0) return RF_OK;
     if (!points || !point_adjacency || !point_adjacency_offsets || !adjacent_diff)
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_build_adjacent_diff: null pointer");
-    hipLaunchKernelGGL(prepare_cells_kernel<false>, dim3((num_points + 255u) / 256u), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), points, static_cast<const void *>(nullptr), 0u,
-                       num_points, point_adjacency, point_adjacency_offsets,
-                       static_cast<RfCell *>(nullptr), static_cast<uint2 *>(adjacent_diff), 0, 1);
+    hipLaunchKernelGGL(adjacent_diff_kernel, dim3((num_points + 255u) / 256u), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), points, num_points, point_adjacency,
+                       point_adjacency_offsets, static_cast<uint2 *>(adjacent_diff));
     return check_launch("rf_build_adjacent_diff");
 }
 
 int rf_prepare_foam(int sh_degree, int attr_type, uint32_t num_points, const float *points,
                     const void *attributes, uint32_t point_adjacency_size,
                     const uint32_t *point_adjacency, const uint32_t *point_adjacency_offsets,
-                    void *workspace, size_t workspace_bytes, void *stream) {
+                    const void *adjacent_diff, void *workspace, size_t workspace_bytes, void *stream) {
     g_err[0] = 0;
     if (!valid_instance(sh_degree, attr_type))
         return fail(RF_ERR_INVALID_ARGUMENT, "Unsupported SH degree or attribute type");
     if (num_points && (!points || !attributes || !point_adjacency || !point_adjacency_offsets))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_prepare_foam: null pointer");
     return prepare_impl(sh_degree, attr_type, num_points, points, attributes, point_adjacency_size,
-                        point_adjacency, point_adjacency_offsets, workspace, workspace_bytes, true,
-                        static_cast<hipStream_t>(stream));
+                        point_adjacency, point_adjacency_offsets, adjacent_diff, workspace,
+                        workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *settings,
@@ -851,7 +1118,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     if (!points || !attributes || !point_adjacency || !point_adjacency_offsets || !rays ||
         !start_point_index || !ray_rgba)
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: null pointer");
-    if (num_depth_quantiles && (!depth_quantiles || !quantile_depths || !quantile_point_indices))
+    if (num_depth_quantiles && depth_quantiles && (!quantile_depths || !quantile_point_indices))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: depth quantile buffers missing");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -860,12 +1127,12 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
         return fail(RF_ERR_WORKSPACE, "workspace missing or smaller than rf_workspace_bytes()");
     if (!opts->foam_prepared) {
         int rc = prepare_impl(sh_degree, attr_type, num_points, points, attributes, point_adjacency_size,
-                              point_adjacency, point_adjacency_offsets, opts->workspace,
-                              opts->workspace_bytes, true, s);
+                              point_adjacency, point_adjacency_offsets, nullptr, opts->workspace,
+                              opts->workspace_bytes, s);
         if (rc != RF_OK) return rc;
     }
     FwdParams p{};
-    p.foam = make_view(L, opts->workspace, attributes, point_adjacency, point_adjacency_size);
+    p.foam = make_view(L, opts->workspace, attributes, point_adjacency_offsets);
     p.grid = make_grid(num_rays, opts);
     p.settings = *settings;
     p.rays = rays;
@@ -901,6 +1168,8 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_point_indices || !depth_grad))
         return fail(RF_ERR_INVALID_ARGUMENT, "depth_grad must be provided if depth_quantiles is provided");
+    if (opts->backward_mode > 2u)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0, 1 or 2");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -908,12 +1177,12 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
         return fail(RF_ERR_WORKSPACE, "workspace missing or smaller than rf_workspace_bytes()");
     if (!opts->foam_prepared) {
         int rc = prepare_impl(sh_degree, attr_type, num_points, points, attributes, point_adjacency_size,
-                              point_adjacency, point_adjacency_offsets, opts->workspace,
-                              opts->workspace_bytes, true, s);
+                              point_adjacency, point_adjacency_offsets, nullptr, opts->workspace,
+                              opts->workspace_bytes, s);
         if (rc != RF_OK) return rc;
     }
     BwdParams p{};
-    p.foam = make_view(L, opts->workspace, attributes, point_adjacency, point_adjacency_size);
+    p.foam = make_view(L, opts->workspace, attributes, point_adjacency_offsets);
     p.grid = make_grid(num_rays, opts);
     p.settings = *settings;
     p.rays = rays;
@@ -928,8 +1197,8 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     p.points_grad = points_grad;
     p.attr_grad = static_cast<float *>(attribute_grad);
     p.point_error = static_cast<float *>(point_error);
-    p.attr_dim = attribute_dim(sh_degree);
-    return dispatch<LaunchBackward>(sh_degree, half, p, s);
+    const int mode = opts->backward_mode == 1u ? 1 : 2;
+    return dispatch<LaunchBackward>(sh_degree, half, p, mode, s);
 }
 
 int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *settings,
@@ -948,24 +1217,20 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
     if (!points || !attributes || !point_adjacency || !point_adjacency_offsets || !adjacent_diff ||
         !start_point_index || !ray_rgba)
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_benchmark: null pointer");
-    if (point_adjacency_size < 2)
-        return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_benchmark: adjacency too small");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
     if (!opts->workspace || opts->workspace_bytes < L.total)
         return fail(RF_ERR_WORKSPACE, "workspace missing or smaller than rf_workspace_bytes()");
     if (!opts->foam_prepared) {
-        // the face table is the caller's: only cell records / SH rows are packed
+        // the half offsets are the CALLER's (benchmark.py:44-54): packed into the fat table as given
         int rc = prepare_impl(sh_degree, attr_type, num_points, points, attributes, point_adjacency_size,
-                              point_adjacency, point_adjacency_offsets, opts->workspace,
-                              opts->workspace_bytes, false, s);
+                              point_adjacency, point_adjacency_offsets, adjacent_diff, opts->workspace,
+                              opts->workspace_bytes, s);
         if (rc != RF_OK) return rc;
     }
     FwdParams p{};
-    p.foam = make_view(L, opts->workspace, attributes, point_adjacency, point_adjacency_size);
-    p.foam.diff = static_cast<const uint2 *>(adjacent_diff);
-    p.foam.diff_count = point_adjacency_size;
+    p.foam = make_view(L, opts->workspace, attributes, point_adjacency_offsets);
     p.grid = RayGrid{camera->width * camera->height, camera->width, camera->height};
     p.settings = *settings;
     p.start = start_point_index;

@@ -9,7 +9,7 @@ memory and the current stream.  There is no CPU path: CPU tensors are rejected w
 reference's "... must be on CUDA device" errors.
 
 Differences from the reference, all documented in DESIGN.md:
-  * the packed foam (cell records + fp16 face table, what the reference rebuilds inside every
+  * the packed foam (cell records + face table, what the reference rebuilds inside every
     trace_forward AND trace_backward call, pipeline.cu:613-620,667-674) is cached on the
     Pipeline while the input tensors are unchanged (same storage, same ``_version``);
   * fp16 pipelines accumulate ``contribution`` / ``attr_grad`` / ``point_error`` in fp32 and
@@ -63,7 +63,8 @@ def _stream_ptr(device):
 
 
 class _FoamCache:
-    """One packed foam per Pipeline, keyed on the identity + version of the input tensors.
+    """One packed foam per Pipeline, keyed on the identity + version of the input tensors
+    (points, attributes, adjacency, offsets and, for trace_benchmark, the caller's half table).
 
     The entry keeps the input tensors alive, so their storage cannot be handed to a different
     tensor while the entry could still be matched.
@@ -73,26 +74,22 @@ class _FoamCache:
         self.key = None
         self.refs = None
         self.workspace = None
-        self.diff_built = False
 
     @staticmethod
     def _key(tensors):
-        return tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device) for t in tensors)
+        return tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device)
+                     for t in tensors)
 
-    def lookup(self, tensors, need_diff):
-        if self.key is not None and self.key == self._key(tensors) and (self.diff_built or not need_diff):
-            return True
-        return False
+    def lookup(self, tensors):
+        return self.key is not None and self.key == self._key(tensors)
 
-    def store(self, tensors, diff_built):
+    def store(self, tensors):
         self.key = self._key(tensors)
         self.refs = tuple(tensors)
-        self.diff_built = diff_built
 
     def clear(self):
         self.key = None
         self.refs = None
-        self.diff_built = False
 
 
 class Pipeline:
@@ -187,13 +184,13 @@ class Pipeline:
         return s
 
     # -- foam packing ---------------------------------------------------------------------------
-    def _launch_opts(self, points, attributes, adjacency, offsets, rays_shape, need_diff=True):
-        """Workspace + rf_launch_opts for this call; runs rf_prepare_foam on a cache miss."""
+    def _launch_opts(self, points, attributes, adjacency, offsets, rays_shape, ext_diff=None):
+        """Workspace + rf_launch_opts for this call (foam_prepared set on a cache hit)."""
         n = points.numel() // 3
         e = adjacency.numel()
         nbytes = int(self._lib.rf_workspace_bytes(n, e, self._sh_degree, self._attr_type))
-        tensors = (points, attributes, adjacency, offsets)
-        hit = self.cache_foam and self._cache.lookup(tensors, need_diff)
+        tensors = (points, attributes, adjacency, offsets, ext_diff)
+        hit = self.cache_foam and self._cache.lookup(tensors)
         ws = self._cache.workspace
         if ws is None or ws.numel() < nbytes or ws.device != points.device:
             ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=points.device)
@@ -209,7 +206,7 @@ class Pipeline:
             opts.image_height, opts.image_width = int(rays_shape[0]), int(rays_shape[1])
         if not hit:
             if self.cache_foam:
-                self._cache.store(tensors, diff_built=need_diff)
+                self._cache.store(tensors)
             else:
                 self._cache.clear()
         return opts
@@ -431,7 +428,7 @@ class Pipeline:
             raise RuntimeError("output_rgba must be contiguous (it is written in place)")
         settings = self._settings(weight_threshold, max_intersections)
 
-        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, (), need_diff=False)
+        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, (), ext_diff=diff_c)
         dev = points_c.device
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_benchmark(
@@ -466,7 +463,8 @@ class Pipeline:
         _lib.check(rc)
         s = stats.cpu().tolist()
         return {"cells_scanned": s[0], "faces_scanned": s[1], "hops": s[2], "segments": s[3],
-                "segments_lit": s[4], "num_rays": num_rays}
+                "segments_lit": s[4], "num_rays": num_rays, "lane_steps_staged_in_lds": s[5],
+                "wave_steps": s[6]}
 
     def build_adjacent_diff(self, points, point_adjacency, point_adjacency_offsets):
         """half4 neighbour-offset table [E,4] (prefetch_adjacent_diff, pipeline.cu:546-586; the

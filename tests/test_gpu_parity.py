@@ -140,7 +140,7 @@ def _backward_case(foam_factory, d, seed, image, quantiles, with_error, n_points
     return fm, rays, starts, q, dg, g, err, fwd, ref
 
 
-@pytest.mark.parametrize("mode", [1])
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("d,image,quantiles,with_error", [
     (0, True, False, False), (1, False, True, True), (2, True, True, False), (2, False, False, True),
     (3, True, False, False), (3, False, True, True),
