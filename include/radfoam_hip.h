@@ -62,10 +62,19 @@ typedef struct rf_launch_opts {
     uint32_t image_width;     /* rays form a row-major [image_height, image_width] grid: lets a wave  */
     uint32_t image_height;    /*   own an 8x8 pixel tile.  0,0 = treat rays as a flat list            */
     uint32_t backward_mode;   /* rf_trace_backward only: 0 = auto, 1 = per-lane atomics, 2 = wave     */
-                              /*   pre-reduced atomics                                                */
+                              /*   pre-reduced atomics, 3 = block-level LDS write-combining (needs    */
+                              /*   the trail; falls back to 2 without it)                             */
     uint64_t *stats;          /* optional device uint64[8]: walk counters for the roofline figure     */
                               /*   [0] cells scanned [1] faces scanned [2] hops [3] segments          */
                               /*   [4] lit segments; accumulated with atomics, caller zeroes          */
+    /* Hop trail (optional): rf_trace_forward records, for every ray, the face entry each hop went   */
+    /* through; rf_trace_backward given the SAME buffers (and the same foam, rays, start cells,       */
+    /* quantiles and settings) replays it instead of re-scanning every cell's faces.  Rays with more  */
+    /* than trail_cap hops are re-scanned past that point, so any trail_cap >= 1 is correct.          */
+    uint32_t *trail;          /* device uint32[trail_cap][trail_slots]                                */
+    uint32_t *trail_hops;     /* device uint32[trail_slots]                                           */
+    uint32_t trail_cap;
+    uint32_t trail_slots;     /* >= rf_trail_slots(num_rays, image_width, image_height)               */
 } rf_launch_opts;
 
 /* Last error message of the calling thread ("" if none). */
@@ -73,6 +82,9 @@ const char *rf_last_error(void);
 
 /* Pipeline::attribute_dim(), pipeline.cu:768-770: 1 + 3*(d+1)^2, or 0 if d is unsupported. */
 uint32_t rf_attribute_dim(int sh_degree);
+
+/* Thread slots a launch over these rays uses (trail buffers are indexed by slot). */
+uint32_t rf_trail_slots(uint32_t num_rays, uint32_t image_width, uint32_t image_height);
 
 /* Bytes of device scratch the tracer needs for a foam of this size: 16-byte cell records,
  * the 16-byte-per-face table (fp16 neighbour offsets as in the reference's half4 table, plus

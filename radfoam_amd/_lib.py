@@ -50,6 +50,10 @@ class LaunchOpts(C.Structure):
         ("image_height", C.c_uint32),
         ("backward_mode", C.c_uint32),
         ("stats", C.c_void_p),
+        ("trail", C.c_void_p),
+        ("trail_hops", C.c_void_p),
+        ("trail_cap", C.c_uint32),
+        ("trail_slots", C.c_uint32),
     ]
 
 
@@ -60,6 +64,7 @@ _INT = C.c_int
 SYMBOLS = {
     "rf_last_error": (C.c_char_p, []),
     "rf_attribute_dim": (_U32, [_INT]),
+    "rf_trail_slots": (_U32, [_U32, _U32, _U32]),
     "rf_workspace_bytes": (C.c_size_t, [_U32, _U32, _INT, _INT]),
     "rf_build_adjacent_diff": (_INT, [_P, _U32, _U32, _P, _P, _P, _P]),
     "rf_prepare_foam": (_INT, [_INT, _INT, _U32, _P, _P, _U32, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -63,6 +63,9 @@ struct FwdParams {
     uint32_t *nint;
     float *contribution;
     unsigned long long *stats;
+    uint32_t *trail;        // [trail_cap][trail_slots] winning face entry per hop (optional)
+    uint32_t *trail_hops;   // [trail_slots] hops taken by the ray of each thread slot
+    uint32_t trail_cap, trail_slots;
     // benchmark
     rf_camera cam;
     float inv_tan_half_fov;
@@ -85,15 +88,18 @@ struct BwdParams {
     float *points_grad;
     float *attr_grad;   // fp32 accumulator [N][A]
     float *point_error; // fp32 accumulator [N]
+    const uint32_t *trail;
+    const uint32_t *trail_hops;
+    uint32_t trail_cap, trail_slots;
 };
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 #ifndef RF_MAX_DISTINCT
-#define RF_MAX_DISTINCT 4
+#define RF_MAX_DISTINCT 16
 #endif
 #ifndef RF_STAGE_CAP
-#define RF_STAGE_CAP 160
+#define RF_STAGE_CAP 400
 #endif
 constexpr int kMaxDistinct = RF_MAX_DISTINCT;  // distinct cells per wave-step staged through LDS
 constexpr int kStageCap = RF_STAGE_CAP;        // fat entries of LDS per wave (16 B each)
@@ -415,6 +421,8 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
     uint32_t my = stage_faces(fv.faces, lds, lane, alive, nb, cnt);
 
     uint32_t wave_steps = 0;
+    uint32_t hops = 0;
+    const uint32_t slot = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     while (ballot(alive) != 0ull) {
         wave_steps++;
         if (alive) {
@@ -443,6 +451,13 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
             nnb = link.y;
             ncnt = sr.w1 >> 16;
             nhead = fv.cells[nxt];
+            if constexpr (!BENCH) {
+                // trail: the face each hop went through, for trace_backward to replay
+                if (p.trail) {
+                    if (hops < p.trail_cap) p.trail[(size_t)hops * p.trail_slots + slot] = nb + sr.k;
+                    hops++;
+                }
+            }
         }
         // every LDS read of this step has been consumed: re-stage for the next step now, so the
         // DMA flies while the segment is composited
@@ -489,6 +504,9 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
     }
     wait_staged();  // no DMA may be in flight into this wave's LDS when the block retires
 
+    if constexpr (!BENCH) {
+        if (p.trail) p.trail_hops[slot] = valid ? hops : 0u;
+    }
     if (!valid) return;
     if constexpr (BENCH) {
         p.rgba8[ray] = make_rgba8(Cr, Cg, Cb, 1.0f);
@@ -539,6 +557,15 @@ __device__ __forceinline__ float load_attr_scalar(const void *base, size_t i) {
     }
 }
 
+// gradient accumulation: hardware fp32 atomic add (global_atomic_add_f32, no return)
+__device__ __forceinline__ void grad_add(float *dst, float v) {
+#ifdef RF_EXPERIMENT_NO_ATOMICS
+    if (v == 123.456f) *dst = v;   // keeps the value computation alive, issues (almost) no memory op
+#else
+    unsafeAtomicAdd(dst, v);
+#endif
+}
+
 constexpr int pow2_at_least(int v) { return v <= 8 ? 8 : (v <= 16 ? 16 : (v <= 32 ? 32 : 64)); }
 
 template <int NB>
@@ -547,7 +574,7 @@ __device__ __forceinline__ void add_row_per_lane(float *dst, const float (&sh)[N
 #pragma unroll
     for (int i = 0; i < 3 * NB; ++i) {
         float gc = (i % 3 == 0) ? dLr : ((i % 3 == 1) ? dLg : dLb);
-        unsafeAtomicAdd(dst + i, sh[i / 3] * gc);
+        grad_add(dst + i, sh[i / 3] * gc);
     }
 }
 
@@ -568,13 +595,13 @@ __device__ __forceinline__ void scatter_step(uint32_t lane, bool has, bool row, 
         if (has) {
             if (pg_on) {
                 float *pg = points_grad + 3 * (size_t)prev;
-                unsafeAtomicAdd(pg + 0, pgx);
-                unsafeAtomicAdd(pg + 1, pgy);
-                unsafeAtomicAdd(pg + 2, pgz);
+                grad_add(pg + 0, pgx);
+                grad_add(pg + 1, pgy);
+                grad_add(pg + 2, pgz);
             }
             float *dst = attr_grad + (size_t)cur * A;
             if (row) add_row_per_lane<NB>(dst, sh, dLr, dLg, dLb);
-            unsafeAtomicAdd(dst + (A - 1), dL_ds);
+            grad_add(dst + (A - 1), dL_ds);
         }
     } else {
         constexpr int NV = pow2_at_least(A + 3);   // row (A values) + point gradient (3)
@@ -611,9 +638,9 @@ __device__ __forceinline__ void scatter_step(uint32_t lane, bool has, bool row, 
                 for (int i = A + 3; i < NV; ++i) v[i] = 0.0f;
                 const float tot = transpose_reduce<NV>(v, lane);
                 if (lane < (uint32_t)A) {
-                    unsafeAtomicAdd(attr_grad + (size_t)c * A + lane, tot);
+                    grad_add(attr_grad + (size_t)c * A + lane, tot);
                 } else if (lane < (uint32_t)(A + 3) && any_pg) {
-                    unsafeAtomicAdd(points_grad + 3 * (size_t)pl + (lane - (uint32_t)A), tot);
+                    grad_add(points_grad + 3 * (size_t)pl + (lane - (uint32_t)A), tot);
                 }
                 if (mine) ds_left = false;
                 if (take_pg) pg_left = false;
@@ -628,19 +655,227 @@ __device__ __forceinline__ void scatter_step(uint32_t lane, bool has, bool row, 
             const bool mine = ds_left && cur == c;
             const uint64_t same = ballot(mine);
             const float tot = wave_sum(mine ? dL_ds : 0.0f);
-            if ((int)lane == leader) unsafeAtomicAdd(attr_grad + (size_t)c * A + (A - 1), tot);
+            if ((int)lane == leader) grad_add(attr_grad + (size_t)c * A + (A - 1), tot);
             todo &= ~same;
         }
         // ---- point gradients that did not ride along
         if (pg_left) {
             float *pg = points_grad + 3 * (size_t)prev;
-            unsafeAtomicAdd(pg + 0, pgx);
-            unsafeAtomicAdd(pg + 1, pgy);
-            unsafeAtomicAdd(pg + 2, pgz);
+            grad_add(pg + 0, pgx);
+            grad_add(pg + 1, pgy);
+            grad_add(pg + 2, pgz);
         }
     }
 }
 
+// Per-ray state of the backward pass (registers).
+struct BwdRay {
+    float Ox, Oy, Oz, dx, dy, dz;
+    float gr, gg, gb, ga, outr, outg, outb, outa, err;
+    float T, Cr, Cg, Cb, t0;
+    uint32_t prev;
+    float ppx, ppy, ppz;   // prev point
+    float pgx, pgy, pgz;   // prev_point_grad
+    float cgx, cgy, cgz;   // current_point_grad
+    float ngx, ngy, ngz;   // next_point_grad
+    uint32_t qi;
+    float cq, cdg;
+    const float *qp;
+    const float *dgp;
+};
+
+// What one composited segment adds to the gradient buffers (scattered later by the whole wave).
+struct StepGrad {
+    bool has, row, pg_on;
+    uint32_t cur, prev;
+    float dLr, dLg, dLb, dL_ds, px, py, pz;
+};
+
+template <int DEG, bool HALF>
+__device__ __forceinline__ void load_backward_ray(const BwdParams &p, uint32_t ray, BwdRay &R, uint32_t &cur) {
+    const FoamView &fv = p.foam;
+    const float *rp = p.rays + (size_t)ray * 6;
+    R.Ox = rp[0];
+    R.Oy = rp[1];
+    R.Oz = rp[2];
+    float dx = rp[3], dy = rp[4], dz = rp[5];
+    float nrm = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+    R.dx = dx / nrm;
+    R.dy = dy / nrm;
+    R.dz = dz / nrm;
+    R.gr = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 0);
+    R.gg = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 1);
+    R.gb = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 2);
+    R.ga = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 3);
+    R.outr = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 0);
+    R.outg = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 1);
+    R.outb = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 2);
+    R.outa = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 3);
+    if (p.ray_error) R.err = load_attr_scalar<HALF>(p.ray_error, ray);
+    cur = p.start[ray];
+    const uint32_t nq = p.nq;
+    if (nq) {
+        R.qp = p.quantiles + (size_t)ray * nq;
+        R.dgp = p.depth_grad + (size_t)ray * nq;
+        R.cq = R.qp[0];
+        for (uint32_t i = 0; i < nq; ++i) {
+            uint32_t ci = p.qidx[(size_t)ray * nq + i];
+            if (ci != kNone) {
+                float s = fv.cells[ci].w;
+                R.cdg += R.dgp[i] / s;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void init_backward_ray(BwdRay &R) {
+    R.Ox = R.Oy = R.Oz = 0.0f;
+    R.dx = R.dy = 0.0f;
+    R.dz = 1.0f;
+    R.gr = R.gg = R.gb = R.ga = R.outr = R.outg = R.outb = R.outa = R.err = 0.0f;
+    R.T = 1.0f;
+    R.Cr = R.Cg = R.Cb = 0.0f;
+    R.t0 = 0.0f;
+    R.prev = kNone;
+    R.ppx = R.ppy = R.ppz = 0.0f;
+    R.pgx = R.pgy = R.pgz = 0.0f;
+    R.cgx = R.cgy = R.cgz = 0.0f;
+    R.ngx = R.ngy = R.ngz = 0.0f;
+    R.qi = 0;
+    R.cq = R.cdg = 0.0f;
+    R.qp = nullptr;
+    R.dgp = nullptr;
+}
+
+// The backward functor for the segment [t0,t1] of cell `cur` (reference: pipeline.cu:180-331).
+// Returns false when the ray terminates (transmittance below the threshold).
+template <int DEG, bool HALF>
+__device__ __forceinline__ bool backward_segment(const BwdParams &p, BwdRay &R, const float (&sh)[sh_dim(DEG)],
+                                                 uint32_t cur, float4 head, float4 nhead, float t1,
+                                                 StepGrad &G) {
+    const FoamView &fv = p.foam;
+    const uint32_t nq = p.nq;
+    const float t0 = R.t0;
+    float s = head.w;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
+    float dt = __builtin_fmaxf(t1 - t0, 0.0f);
+    float alpha = 1.0f - exp_(-s * dt);
+    float w = R.T * alpha;
+    float da_ds = dt * (1.0f - alpha);
+    float da_ddt = (dt > 0.0f) ? s * (1.0f - alpha) : 0.0f;
+
+    R.Cr = fma_(w, r, R.Cr);
+    R.Cg = fma_(w, g, R.Cg);
+    R.Cb = fma_(w, b, R.Cb);
+    if (p.point_error) unsafeAtomicAdd(p.point_error + cur, w * R.err);
+
+    float dLr = R.gr * w, dLg = R.gg * w, dLb = R.gb * w;
+    float den = R.T * ((1.0f - alpha) + 1e-6f);
+    float dfr = r - (R.outr - R.Cr) / den;
+    float dfg = g - (R.outg - R.Cg) / den;
+    float dfb = b - (R.outb - R.Cb) / den;
+    float dL_da = R.T * dot3(dfr, dfg, dfb, R.gr, R.gg, R.gb);
+    dL_da = dL_da + ((1.0f - R.outa) * R.ga) / ((1.0f - alpha) + 1e-6f);
+
+    float dL_ds = dL_da * da_ds;
+    float dL_ddt = dL_da * da_ddt;
+    float dL_dt0 = 0.0f;
+
+    float Tn = R.T * (1.0f - alpha);
+    while (R.qi < nq && Tn < R.cq) {
+        float gi = R.dgp[R.qi] / s;
+        dL_dt0 = dL_dt0 + gi;
+        dL_ds = dL_ds + ((-gi) * log_(R.T / R.cq)) / s;
+        R.cdg = R.cdg - gi;
+        R.qi++;
+        if (R.qi < nq) R.cq = R.qp[R.qi];
+    }
+    if (R.qi < nq) {
+        dL_ds = fma_(-dt, R.cdg, dL_ds);
+        dL_ddt = fma_(-s, R.cdg, dL_ddt);
+    }
+    dL_dt0 = dL_dt0 + (-dL_ddt);
+    float dL_dt1 = dL_ddt;
+
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;  // dt0_dprev
+    if (R.prev != kNone)
+        bisector_grad(R.ppx, R.ppy, R.ppz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ax, ay, az);
+    float bx, by, bz;                        // dt1_dcurrent
+    bisector_grad(head.x, head.y, head.z, nhead.x, nhead.y, nhead.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, bx, by, bz);
+    float ex, ey, ez;                        // dt0_dcurrent (vs prev, or vs origin on the first segment)
+    bisector_grad(head.x, head.y, head.z, R.ppx, R.ppy, R.ppz, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ex, ey, ez);
+    float fx, fy, fz;                        // dt1_dnext
+    bisector_grad(nhead.x, nhead.y, nhead.z, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, fx, fy, fz);
+
+    R.pgx = fma_(dL_dt0, ax, R.pgx);
+    R.pgy = fma_(dL_dt0, ay, R.pgy);
+    R.pgz = fma_(dL_dt0, az, R.pgz);
+    R.cgx = R.cgx + fma_(dL_dt0, ex, dL_dt1 * bx);
+    R.cgy = R.cgy + fma_(dL_dt0, ey, dL_dt1 * by);
+    R.cgz = R.cgz + fma_(dL_dt0, ez, dL_dt1 * bz);
+    R.ngx = fma_(dL_dt1, fx, R.ngx);
+    R.ngy = fma_(dL_dt1, fy, R.ngy);
+    R.ngz = fma_(dL_dt1, fz, R.ngz);
+
+    // what the reference adds with atomics at this point (pipeline.cu:305-328): prev_point_grad ->
+    // points_grad[prev]; the SH row and dL/ds -> attr_grad[cur].  Exact zeros are not added.
+    G.has = true;
+    G.cur = cur;
+    G.prev = R.prev;
+    G.px = R.pgx;
+    G.py = R.pgy;
+    G.pz = R.pgz;
+    G.pg_on = (R.prev != kNone) && (R.pgx != 0.0f || R.pgy != 0.0f || R.pgz != 0.0f);
+    if (r == 0.0f) dLr = 0.0f;
+    if (g == 0.0f) dLg = 0.0f;
+    if (b == 0.0f) dLb = 0.0f;
+    G.dLr = dLr;
+    G.dLg = dLg;
+    G.dLb = dLb;
+    G.dL_ds = dL_ds;
+    G.row = (dLr != 0.0f || dLg != 0.0f || dLb != 0.0f);
+
+    R.ppx = head.x;
+    R.ppy = head.y;
+    R.ppz = head.z;
+    R.prev = cur;
+    R.pgx = R.cgx;
+    R.pgy = R.cgy;
+    R.pgz = R.cgz;
+    R.cgx = R.ngx;
+    R.cgy = R.ngy;
+    R.cgz = R.ngz;
+    R.ngx = R.ngy = R.ngz = 0.0f;
+    R.T = Tn;
+    return Tn > p.settings.weight_threshold;
+}
+
+__device__ __forceinline__ void clear_step(StepGrad &G) {
+    G.has = G.row = G.pg_on = false;
+    G.cur = 0;
+    G.prev = kNone;
+    G.dLr = G.dLg = G.dLb = G.dL_ds = G.px = G.py = G.pz = 0.0f;
+}
+
+template <int DEG, int MODE>
+__device__ __forceinline__ void scatter_pending(const BwdParams &p, uint32_t lane, const float (&sh)[sh_dim(DEG)],
+                                                StepGrad &G) {
+#ifdef RF_EXPERIMENT_NO_SCATTER
+    if (G.has && G.dL_ds == 123.456f) p.attr_grad[0] = G.dLr + G.dLg + G.dLb + G.px + G.py + G.pz;
+    G.has = false;
+    return;
+#endif
+    if (ballot(G.has) != 0ull) {
+        scatter_step<DEG, MODE>(lane, G.has, G.row, G.cur, sh, G.dLr, G.dLg, G.dLb, G.dL_ds, G.pg_on, G.prev,
+                                G.px, G.py, G.pz, p.attr_grad, p.points_grad);
+    }
+    G.has = false;
+    G.row = false;
+    G.pg_on = false;
+}
+
+// Backward by re-walking (no trail available): same scan as forward.
 template <int DEG, bool HALF, int MODE>
 __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
     __shared__ uint4 s_faces[kWaves * kStageCap + 8];
@@ -652,63 +887,14 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
     const FoamView &fv = p.foam;
     constexpr int NB = sh_dim(DEG);
 
-    float Ox = 0.0f, Oy = 0.0f, Oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 1.0f;
-    float gr = 0.0f, gg = 0.0f, gb = 0.0f, ga = 0.0f, outr = 0.0f, outg = 0.0f, outb = 0.0f, outa = 0.0f;
-    float err = 0.0f;
+    BwdRay R;
+    init_backward_ray(R);
     uint32_t cur = 0;
-    const uint32_t nq = p.nq;
-    uint32_t qi = 0;
-    const float *qp = nullptr;
-    const float *dgp = nullptr;
-    float cq = 0.0f, cdg = 0.0f;
-    if (alive) {
-        const float *rp = p.rays + (size_t)ray * 6;
-        Ox = rp[0];
-        Oy = rp[1];
-        Oz = rp[2];
-        dx = rp[3];
-        dy = rp[4];
-        dz = rp[5];
-        float nrm = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
-        dx = dx / nrm;
-        dy = dy / nrm;
-        dz = dz / nrm;
-        gr = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 0);
-        gg = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 1);
-        gb = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 2);
-        ga = load_attr_scalar<HALF>(p.rgba_grad, (size_t)ray * 4 + 3);
-        outr = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 0);
-        outg = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 1);
-        outb = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 2);
-        outa = load_attr_scalar<HALF>(p.rgba, (size_t)ray * 4 + 3);
-        if (p.ray_error) err = load_attr_scalar<HALF>(p.ray_error, ray);
-        cur = p.start[ray];
-        if (nq) {
-            qp = p.quantiles + (size_t)ray * nq;
-            dgp = p.depth_grad + (size_t)ray * nq;
-            cq = qp[0];
-            for (uint32_t i = 0; i < nq; ++i) {
-                uint32_t ci = p.qidx[(size_t)ray * nq + i];
-                if (ci != kNone) {
-                    float s = fv.cells[ci].w;
-                    cdg += dgp[i] / s;
-                }
-            }
-        }
-    }
+    if (alive) load_backward_ray<DEG, HALF>(p, ray, R, cur);
     float sh[NB];
-    sh_basis<DEG>(dx, dy, dz, sh);
-    const float thr = p.settings.weight_threshold;
+    sh_basis<DEG>(R.dx, R.dy, R.dz, sh);
     const uint32_t max_steps = p.settings.max_intersections;
 
-    float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
-    uint32_t prev = kNone;
-    float ppx = 0.0f, ppy = 0.0f, ppz = 0.0f;          // prev point
-    float pgx = 0.0f, pgy = 0.0f, pgz = 0.0f;          // prev_point_grad
-    float cgx = 0.0f, cgy = 0.0f, cgz = 0.0f;          // current_point_grad
-    float ngx = 0.0f, ngy = 0.0f, ngz = 0.0f;          // next_point_grad
-
-    float t0 = 0.0f;
     uint32_t n = 0;
     uint32_t nb = 0, cnt = 0;
     float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -719,13 +905,12 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
     }
     uint32_t my = stage_faces(fv.faces, lds, lane, alive, nb, cnt);
 
-    // Gradient contributions of the step just finished.  They are scattered at the top of the
-    // NEXT iteration, right after the wait for the staged faces: the atomics then complete
-    // under the long face scan instead of sitting in front of the next wait (memory operations
-    // retire in order, so an atomic issued after the stage DMA would otherwise delay it).
-    bool has = false, row = false, pg_on = false;
-    uint32_t s_cur = 0, s_prev = kNone;
-    float dLr = 0.0f, dLg = 0.0f, dLb = 0.0f, dL_ds = 0.0f, fpx = 0.0f, fpy = 0.0f, fpz = 0.0f;
+    // Gradient contributions of the step just finished are scattered at the top of the NEXT
+    // iteration, right after the wait for the staged faces: the atomics then complete under the
+    // long face scan instead of sitting in front of the next wait (memory operations retire in
+    // order, so an atomic issued after the stage DMA would otherwise delay it).
+    StepGrad G;
+    clear_step(G);
 
     while (ballot(alive) != 0ull) {
         if (alive) {
@@ -733,19 +918,13 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
             if (n > max_steps) alive = false;
         }
         wait_staged();
-        if (ballot(has) != 0ull) {
-            scatter_step<DEG, MODE>(lane, has, row, s_cur, sh, dLr, dLg, dLb, dL_ds, pg_on, s_prev, fpx, fpy,
-                                    fpz, p.attr_grad, p.points_grad);
-        }
-        has = false;
-        row = false;
-        pg_on = false;
+        scatter_pending<DEG, MODE>(p, lane, sh, G);
         ScanResult sr;
         sr.t1 = __builtin_inff();
         sr.k = kNone;
         sr.w1 = 0u;
         if (alive) {
-            sr = scan_cell(fv.faces, lds, my, nb, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
+            sr = scan_cell(fv.faces, lds, my, nb, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
             if (sr.k == kNone) alive = false;
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
@@ -758,104 +937,12 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
             nhead = fv.cells[nxt];
         }
         const uint32_t nmy = stage_faces(fv.faces, lds, lane, alive, nnb, ncnt);
-
         if (alive) {
             const float t1 = sr.t1;
-            if (t1 > t0) {
-                float s = head.w;
-                float r = 0.0f, g = 0.0f, b = 0.0f;
-                if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
-                float dt = __builtin_fmaxf(t1 - t0, 0.0f);
-                float alpha = 1.0f - exp_(-s * dt);
-                float w = T * alpha;
-                float da_ds = dt * (1.0f - alpha);
-                float da_ddt = (dt > 0.0f) ? s * (1.0f - alpha) : 0.0f;
-
-                Cr = fma_(w, r, Cr);
-                Cg = fma_(w, g, Cg);
-                Cb = fma_(w, b, Cb);
-                if (p.point_error) unsafeAtomicAdd(p.point_error + cur, w * err);
-
-                dLr = gr * w;
-                dLg = gg * w;
-                dLb = gb * w;
-                float den = T * ((1.0f - alpha) + 1e-6f);
-                float dfr = r - (outr - Cr) / den;
-                float dfg = g - (outg - Cg) / den;
-                float dfb = b - (outb - Cb) / den;
-                float dL_da = T * dot3(dfr, dfg, dfb, gr, gg, gb);
-                dL_da = dL_da + ((1.0f - outa) * ga) / ((1.0f - alpha) + 1e-6f);
-
-                dL_ds = dL_da * da_ds;
-                float dL_ddt = dL_da * da_ddt;
-                float dL_dt0 = 0.0f;
-
-                float Tn = T * (1.0f - alpha);
-                while (qi < nq && Tn < cq) {
-                    float gi = dgp[qi] / s;
-                    dL_dt0 = dL_dt0 + gi;
-                    dL_ds = dL_ds + ((-gi) * log_(T / cq)) / s;
-                    cdg = cdg - gi;
-                    qi++;
-                    if (qi < nq) cq = qp[qi];
-                }
-                if (qi < nq) {
-                    dL_ds = fma_(-dt, cdg, dL_ds);
-                    dL_ddt = fma_(-s, cdg, dL_ddt);
-                }
-                dL_dt0 = dL_dt0 + (-dL_ddt);
-                float dL_dt1 = dL_ddt;
-
-                float ax = 0.0f, ay = 0.0f, az = 0.0f;  // dt0_dprev
-                if (prev != kNone)
-                    bisector_grad(ppx, ppy, ppz, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, ax, ay, az);
-                float bx, by, bz;                        // dt1_dcurrent
-                bisector_grad(head.x, head.y, head.z, nhead.x, nhead.y, nhead.z, Ox, Oy, Oz, dx, dy, dz, bx, by, bz);
-                float ex, ey, ez;                        // dt0_dcurrent (vs prev, or vs origin on the first segment)
-                bisector_grad(head.x, head.y, head.z, ppx, ppy, ppz, Ox, Oy, Oz, dx, dy, dz, ex, ey, ez);
-                float fx, fy, fz;                        // dt1_dnext
-                bisector_grad(nhead.x, nhead.y, nhead.z, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, fx, fy, fz);
-
-                pgx = fma_(dL_dt0, ax, pgx);
-                pgy = fma_(dL_dt0, ay, pgy);
-                pgz = fma_(dL_dt0, az, pgz);
-                cgx = cgx + fma_(dL_dt0, ex, dL_dt1 * bx);
-                cgy = cgy + fma_(dL_dt0, ey, dL_dt1 * by);
-                cgz = cgz + fma_(dL_dt0, ez, dL_dt1 * bz);
-                ngx = fma_(dL_dt1, fx, ngx);
-                ngy = fma_(dL_dt1, fy, ngy);
-                ngz = fma_(dL_dt1, fz, ngz);
-
-                // what the reference adds with atomics at this point (pipeline.cu:305-328):
-                // prev_point_grad -> points_grad[prev]; the SH row and dL/ds -> attr_grad[cur].
-                // Exact zeros are not added (adding +0 changes nothing).
-                has = true;
-                s_cur = cur;
-                s_prev = prev;
-                fpx = pgx;
-                fpy = pgy;
-                fpz = pgz;
-                pg_on = (prev != kNone) && (pgx != 0.0f || pgy != 0.0f || pgz != 0.0f);
-                if (r == 0.0f) dLr = 0.0f;
-                if (g == 0.0f) dLg = 0.0f;
-                if (b == 0.0f) dLb = 0.0f;
-                row = (dLr != 0.0f || dLg != 0.0f || dLb != 0.0f);
-
-                ppx = head.x;
-                ppy = head.y;
-                ppz = head.z;
-                prev = cur;
-                pgx = cgx;
-                pgy = cgy;
-                pgz = cgz;
-                cgx = ngx;
-                cgy = ngy;
-                cgz = ngz;
-                ngx = ngy = ngz = 0.0f;
-                T = Tn;
-                if (!(T > thr)) alive = false;
+            if (t1 > R.t0) {
+                if (!backward_segment<DEG, HALF>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
             }
-            t0 = __builtin_fmaxf(t0, t1);
+            R.t0 = __builtin_fmaxf(R.t0, t1);
             cur = nxt;
             head = nhead;
             nb = nnb;
@@ -864,9 +951,339 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
         }
     }
     wait_staged();
-    if (ballot(has) != 0ull) {
-        scatter_step<DEG, MODE>(lane, has, row, s_cur, sh, dLr, dLg, dLb, dL_ds, pg_on, s_prev, fpx, fpy, fpz,
-                                p.attr_grad, p.points_grad);
+    scatter_pending<DEG, MODE>(p, lane, sh, G);
+}
+
+// Backward by replaying the trail trace_forward recorded for exactly these rays: hop i of a ray
+// went through fat face entry trail[i]; its t1 is recomputed with the same arithmetic (so it
+// is the same float), and no face list is scanned.  Entries, and the next cell's record, are
+// fetched two / one hops ahead.  A ray with more hops than the trail holds re-scans its cells
+// from global memory past that point.
+template <int DEG, bool HALF, int MODE>
+__global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t ray;
+    bool alive = map_ray(p.grid, ray);
+    const FoamView &fv = p.foam;
+    constexpr int NB = sh_dim(DEG);
+    const uint32_t slot = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    const size_t slots = p.trail_slots;
+    const uint32_t cap = p.trail_cap;
+
+    BwdRay R;
+    init_backward_ray(R);
+    uint32_t cur = 0;
+    uint32_t hops = 0;
+    if (alive) {
+        load_backward_ray<DEG, HALF>(p, ray, R, cur);
+        hops = p.trail_hops[slot];
+    }
+    float sh[NB];
+    sh_basis<DEG>(R.dx, R.dy, R.dz, sh);
+    const uint32_t max_steps = p.settings.max_intersections;
+    const uint32_t recorded = hops < cap ? hops : cap;   // hops present in the trail
+
+    // pipeline registers: e2 = trail[i+2], ent1 = faces[trail[i+1]], ent0 = faces[trail[i]],
+    // q0 = cells[ent0.z]
+    float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint4 ent0 = make_uint4(0u, 0u, 0u, 0u), ent1 = make_uint4(0u, 0u, 0u, 0u);
+    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t e2 = 0;
+    uint32_t nb = 0, cnt = 0;   // face range of the current cell (needed past the trail only)
+    if (alive) {
+        head = fv.cells[cur];
+        nb = fv.offsets[cur];
+        cnt = fv.offsets[cur + 1] - nb;
+        if (recorded > 0) ent0 = fv.faces[p.trail[slot]];
+        if (recorded > 1) ent1 = fv.faces[p.trail[slots + slot]];
+        if (recorded > 2) e2 = p.trail[2 * slots + slot];
+        if (recorded > 0) q0 = fv.cells[ent0.z];
+    }
+
+    StepGrad G;
+    clear_step(G);
+    uint32_t i = 0;   // hop index
+    uint32_t n = 0;
+    // Order inside an iteration: (A) issue the prefetch loads, (B) compute the step from data
+    // already in registers, (C) pin the prefetched values (the only wait), (D) scatter.  Memory
+    // operations retire in order, so a load issued after an atomic cannot complete before it:
+    // with this order the atomics of step i retire under the compute of step i+1 instead of
+    // being waited for.
+    while (ballot(alive) != 0ull) {
+        if (alive) {
+            n++;
+            if (n > max_steps) alive = false;
+        }
+        if (alive && i >= hops) alive = false;   // forward stopped here (no exit face / step cap / opaque)
+        // (A) prefetch: cell record of hop i+1, face entry of hop i+2, trail entry of hop i+3
+        float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint4 ent2 = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t e3 = 0;
+        if (alive) {
+            if (i + 1 < recorded) q1 = fv.cells[ent1.z];
+            if (i + 2 < recorded) ent2 = fv.faces[e2];
+            if (i + 3 < recorded) e3 = p.trail[(size_t)(i + 3) * slots + slot];
+        }
+        // (B) this hop
+        uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+        float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float t1 = 0.0f;
+        if (alive) {
+            if (i < recorded) {
+                ent = ent0;
+                nhead = q0;
+                float dp;
+                face_hit(make_uint2(ent.x, ent.y), head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
+            } else {
+                // past the recorded trail: scan this cell from global memory
+                ScanResult sr = scan_faces<false>(fv.faces + nb, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz,
+                                                  R.dx, R.dy, R.dz);
+                if (sr.k == kNone) {
+                    alive = false;
+                } else {
+                    ent = fv.faces[nb + sr.k];
+                    nhead = fv.cells[ent.z];
+                    t1 = sr.t1;
+                }
+            }
+        }
+        if (alive) {
+            if (t1 > R.t0) {
+                if (!backward_segment<DEG, HALF>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
+            }
+            R.t0 = __builtin_fmaxf(R.t0, t1);
+            cur = ent.z;
+            nb = ent.w;
+            cnt = ent.y >> 16;
+            head = nhead;
+            i++;
+        }
+        // (C) rotate the pipeline; the asm pins make the loads complete HERE, before the atomics
+        ent0 = ent1;
+        ent1 = ent2;
+        q0 = q1;
+        e2 = e3;
+        asm volatile("" : "+v"(ent1.x), "+v"(ent1.y), "+v"(ent1.z), "+v"(ent1.w));
+        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(e2));
+        // (D) scatter this hop's gradients
+        scatter_pending<DEG, MODE>(p, lane, sh, G);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MODE 3: block-level gradient write-combining cache.
+//
+// Global fp32 atomics on this part execute at the memory side of the fabric (the XCD L2 drops the
+// line), at a few 10^9 requests/s chip-wide -- far fewer than the (ray, step) contributions of a
+// frame.  The four waves of a block walk one 16x16 pixel tile, i.e. the same few hundred cells
+// within a few steps of each other, so their contributions are first summed in LDS:
+//   * a direct-mapped (two probes) table of kCacheRows rows keyed by cell id; a row holds the A
+//     attribute gradients of the cell followed by its 3 point-gradient components;
+//   * lanes add with LDS atomics (ds_add_f32); a lane whose key finds no free row adds straight
+//     to global memory instead;
+//   * every kEpoch steps the block synchronises and flushes the rows that were not touched during
+//     the epoch (the walk has moved past those cells) with one coalesced row of global atomics,
+//     skipping zeros; rows still in use stay.  At the end everything is flushed.
+
+constexpr int kCacheRows = 256;
+constexpr int kCacheBits = 8;
+constexpr int kEpoch = 8;
+
+__device__ __forceinline__ int cache_find(uint32_t *keys, uint32_t key) {
+    const uint32_t h = (key * 2654435761u) >> (32 - kCacheBits);
+#pragma unroll
+    for (int probe = 0; probe < 2; ++probe) {
+        const uint32_t slot = (h + (uint32_t)probe) & (uint32_t)(kCacheRows - 1);
+        const uint32_t old = atomicCAS(&keys[slot], kNone, key);
+        if (old == kNone || old == key) return (int)slot;
+    }
+    return -1;
+}
+
+// Flush rows to global memory (whole block, between barriers).  all == false: only rows whose
+// touch flag is clear; the flags of the others are cleared for the next epoch.
+template <int A>
+__device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint32_t *touch, bool all,
+                                            float *attr_grad, float *points_grad) {
+    constexpr int NVAL = A + 3;
+    constexpr int STRIDE = NVAL | 1;
+    const uint32_t half = threadIdx.x >> 5, col0 = threadIdx.x & 31u;
+    for (uint32_t r = half; r < (uint32_t)kCacheRows; r += (uint32_t)(kBlock / 32)) {
+        const uint32_t key = keys[r];
+        if (key == kNone) continue;
+        const bool evict = all || touch[r] == 0u;
+        if (evict) {
+            for (uint32_t col = col0; col < (uint32_t)NVAL; col += 32u) {
+                float *cell = rows + r * STRIDE + col;
+                const float v = *cell;
+                if (v != 0.0f) {
+                    *cell = 0.0f;
+                    float *dst = (col < (uint32_t)A) ? attr_grad + (size_t)key * A + col
+                                                      : points_grad + 3 * (size_t)key + (col - (uint32_t)A);
+                    grad_add(dst, v);
+                }
+            }
+            if (col0 == 0u) keys[r] = kNone;
+        } else if (col0 == 0u) {
+            touch[r] = 0u;
+        }
+    }
+}
+
+template <int DEG, bool HALF>
+__global__ __launch_bounds__(kBlock) void backward_replay_cached_kernel(BwdParams p) {
+    constexpr int NB = sh_dim(DEG);
+    constexpr int A = 1 + 3 * NB;
+    constexpr int NVAL = A + 3;
+    constexpr int STRIDE = NVAL | 1;
+    __shared__ float s_rows[kCacheRows * STRIDE];
+    __shared__ uint32_t s_keys[kCacheRows];
+    __shared__ uint32_t s_touch[kCacheRows];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(kCacheRows * STRIDE); i += kBlock) s_rows[i] = 0.0f;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kCacheRows; i += kBlock) {
+        s_keys[i] = kNone;
+        s_touch[i] = 0u;
+    }
+    __syncthreads();
+
+    uint32_t ray;
+    bool alive = map_ray(p.grid, ray);
+    const FoamView &fv = p.foam;
+    const uint32_t slot = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    const size_t slots = p.trail_slots;
+    const uint32_t cap = p.trail_cap;
+
+    BwdRay R;
+    init_backward_ray(R);
+    uint32_t cur = 0;
+    uint32_t hops = 0;
+    if (alive) {
+        load_backward_ray<DEG, HALF>(p, ray, R, cur);
+        hops = p.trail_hops[slot];
+    }
+    float sh[NB];
+    sh_basis<DEG>(R.dx, R.dy, R.dz, sh);
+    const uint32_t max_steps = p.settings.max_intersections;
+    const uint32_t recorded = hops < cap ? hops : cap;
+
+    float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint4 ent0 = make_uint4(0u, 0u, 0u, 0u), ent1 = make_uint4(0u, 0u, 0u, 0u);
+    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t e2 = 0;
+    uint32_t nb = 0, cnt = 0;
+    if (alive) {
+        head = fv.cells[cur];
+        nb = fv.offsets[cur];
+        cnt = fv.offsets[cur + 1] - nb;
+        if (recorded > 0) ent0 = fv.faces[p.trail[slot]];
+        if (recorded > 1) ent1 = fv.faces[p.trail[slots + slot]];
+        if (recorded > 2) e2 = p.trail[2 * slots + slot];
+        if (recorded > 0) q0 = fv.cells[ent0.z];
+    }
+
+    StepGrad G;
+    clear_step(G);
+    uint32_t i = 0;
+    uint32_t n = 0;
+    uint32_t it = 0;
+    bool block_alive = true;
+    while (block_alive) {
+        if (ballot(alive) != 0ull) {
+            if (alive) {
+                n++;
+                if (n > max_steps) alive = false;
+            }
+            if (alive && i >= hops) alive = false;
+            float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            uint4 ent2 = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t e3 = 0;
+            if (alive) {
+                if (i + 1 < recorded) q1 = fv.cells[ent1.z];
+                if (i + 2 < recorded) ent2 = fv.faces[e2];
+                if (i + 3 < recorded) e3 = p.trail[(size_t)(i + 3) * slots + slot];
+            }
+            uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+            float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float t1 = 0.0f;
+            if (alive) {
+                if (i < recorded) {
+                    ent = ent0;
+                    nhead = q0;
+                    float dp;
+                    face_hit(make_uint2(ent.x, ent.y), head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
+                } else {
+                    ScanResult sr = scan_faces<false>(fv.faces + nb, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz,
+                                                      R.dx, R.dy, R.dz);
+                    if (sr.k == kNone) {
+                        alive = false;
+                    } else {
+                        ent = fv.faces[nb + sr.k];
+                        nhead = fv.cells[ent.z];
+                        t1 = sr.t1;
+                    }
+                }
+            }
+            if (alive) {
+                if (t1 > R.t0) {
+                    if (!backward_segment<DEG, HALF>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
+                }
+                R.t0 = __builtin_fmaxf(R.t0, t1);
+                cur = ent.z;
+                nb = ent.w;
+                cnt = ent.y >> 16;
+                head = nhead;
+                i++;
+            }
+            ent0 = ent1;
+            ent1 = ent2;
+            q0 = q1;
+            e2 = e3;
+
+            // add this hop's gradients to the block cache (or straight to memory on a table conflict)
+            if (G.has) {
+                const int s_row = cache_find(s_keys, G.cur);
+                if (s_row >= 0) {
+                    s_touch[s_row] = 1u;
+                    float *dst = s_rows + s_row * STRIDE;
+                    if (G.row) {
+#pragma unroll
+                        for (int k = 0; k < 3 * NB; ++k) {
+                            float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
+                            atomicAdd(dst + k, sh[k / 3] * gc);
+                        }
+                    }
+                    atomicAdd(dst + (A - 1), G.dL_ds);
+                } else {
+                    float *dst = p.attr_grad + (size_t)G.cur * A;
+                    if (G.row) add_row_per_lane<NB>(dst, sh, G.dLr, G.dLg, G.dLb);
+                    grad_add(dst + (A - 1), G.dL_ds);
+                }
+                if (G.pg_on) {
+                    const int s_pg = cache_find(s_keys, G.prev);
+                    if (s_pg >= 0) {
+                        s_touch[s_pg] = 1u;
+                        float *dst = s_rows + s_pg * STRIDE + A;
+                        atomicAdd(dst + 0, G.px);
+                        atomicAdd(dst + 1, G.py);
+                        atomicAdd(dst + 2, G.pz);
+                    } else {
+                        float *dst = p.points_grad + 3 * (size_t)G.prev;
+                        grad_add(dst + 0, G.px);
+                        grad_add(dst + 1, G.py);
+                        grad_add(dst + 2, G.pz);
+                    }
+                }
+            }
+            G.has = false;
+            G.row = false;
+            G.pg_on = false;
+        }
+        it++;
+        if ((it & (uint32_t)(kEpoch - 1)) == 0u) {
+            block_alive = __syncthreads_or(alive ? 1 : 0) != 0;
+            cache_flush<A>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad);
+            __syncthreads();
+        }
     }
 }
 
@@ -1037,10 +1454,19 @@ struct LaunchBackward {
     static int run(const BwdParams &p, int mode, hipStream_t stream) {
         uint32_t nb = grid_blocks(p.grid);
         if (nb == 0) return RF_OK;
-        if (mode == 1)
-            hipLaunchKernelGGL((backward_kernel<DEG, HALF, 1>), dim3(nb), dim3(kBlock), 0, stream, p);
-        else
-            hipLaunchKernelGGL((backward_kernel<DEG, HALF, 2>), dim3(nb), dim3(kBlock), 0, stream, p);
+        if (p.trail) {
+            if (mode == 1)
+                hipLaunchKernelGGL((backward_replay_kernel<DEG, HALF, 1>), dim3(nb), dim3(kBlock), 0, stream, p);
+            else if (mode == 2)
+                hipLaunchKernelGGL((backward_replay_kernel<DEG, HALF, 2>), dim3(nb), dim3(kBlock), 0, stream, p);
+            else
+                hipLaunchKernelGGL((backward_replay_cached_kernel<DEG, HALF>), dim3(nb), dim3(kBlock), 0, stream, p);
+        } else {
+            if (mode == 1)
+                hipLaunchKernelGGL((backward_kernel<DEG, HALF, 1>), dim3(nb), dim3(kBlock), 0, stream, p);
+            else
+                hipLaunchKernelGGL((backward_kernel<DEG, HALF, 2>), dim3(nb), dim3(kBlock), 0, stream, p);
+        }
         return check_launch("rf_trace_backward");
     }
 };
@@ -1067,6 +1493,13 @@ extern "C" {
 const char *rf_last_error(void) { return g_err; }
 
 uint32_t rf_attribute_dim(int sh_degree) { return attribute_dim(sh_degree); }
+
+uint32_t rf_trail_slots(uint32_t num_rays, uint32_t image_width, uint32_t image_height) {
+    rf_launch_opts o{};
+    o.image_width = image_width;
+    o.image_height = image_height;
+    return grid_blocks(make_grid(num_rays, &o)) * (uint32_t)kBlock;
+}
 
 size_t rf_workspace_bytes(uint32_t num_points, uint32_t point_adjacency_size, int sh_degree,
                           int attr_type) {
@@ -1145,6 +1578,14 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     p.nint = num_intersections;
     p.contribution = static_cast<float *>(point_contribution);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
+    if (opts->trail && opts->trail_hops && opts->trail_cap) {
+        if (opts->trail_slots < grid_blocks(p.grid) * (uint32_t)kBlock)
+            return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: trail_slots smaller than rf_trail_slots()");
+        p.trail = opts->trail;
+        p.trail_hops = opts->trail_hops;
+        p.trail_cap = opts->trail_cap;
+        p.trail_slots = opts->trail_slots;
+    }
     return dispatch<LaunchForward>(sh_degree, half, p, false, s);
 }
 
@@ -1168,8 +1609,8 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_point_indices || !depth_grad))
         return fail(RF_ERR_INVALID_ARGUMENT, "depth_grad must be provided if depth_quantiles is provided");
-    if (opts->backward_mode > 2u)
-        return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0, 1 or 2");
+    if (opts->backward_mode > 3u)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0..3");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -1197,7 +1638,18 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     p.points_grad = points_grad;
     p.attr_grad = static_cast<float *>(attribute_grad);
     p.point_error = static_cast<float *>(point_error);
-    const int mode = opts->backward_mode == 1u ? 1 : 2;
+    if (opts->trail && opts->trail_hops && opts->trail_cap) {
+        if (opts->trail_slots < grid_blocks(p.grid) * (uint32_t)kBlock)
+            return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: trail_slots smaller than rf_trail_slots()");
+        p.trail = opts->trail;
+        p.trail_hops = opts->trail_hops;
+        p.trail_cap = opts->trail_cap;
+        p.trail_slots = opts->trail_slots;
+    }
+    // 0 = auto: block-cached scatter when a trail is replayed, wave-reduced scatter otherwise
+    int mode = (int)opts->backward_mode;
+    if (mode == 0) mode = p.trail ? 3 : 2;
+    if (mode == 3 && !p.trail) mode = 2;
     return dispatch<LaunchBackward>(sh_degree, half, p, mode, s);
 }
 

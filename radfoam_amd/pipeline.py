@@ -110,6 +110,13 @@ class Pipeline:
         self.cache_foam = True
         #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics (rf_launch_opts.backward_mode)
         self.backward_mode = 0
+        #: trace_forward records the face every hop went through so that a trace_backward call on
+        #: the same inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).
+        #: Costs trail_steps * 4 bytes per ray of HBM (2.1 GB for a 1080p frame at 256 steps).
+        self.record_trail = True
+        #: hops recorded per ray; rays that take more are re-scanned past this point
+        self.trail_steps = 256
+        self._trail = None
 
     # -- introspection (Pipeline::attribute_dim / attribute_type, pipeline.cu:768-774) ----------
     def attribute_dim(self) -> int:
@@ -211,6 +218,31 @@ class Pipeline:
                 self._cache.clear()
         return opts
 
+    # -- hop trail -------------------------------------------------------------------------------
+    @staticmethod
+    def _tkey(t):
+        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device)
+
+    def _trail_key(self, foam, rays, start, quantiles, settings):
+        return (tuple(self._tkey(t) for t in foam), self._tkey(rays), self._tkey(start), self._tkey(quantiles),
+                float(settings.weight_threshold), int(settings.max_intersections))
+
+    def _new_trail(self, opts, num_rays, dev):
+        slots = int(self._lib.rf_trail_slots(num_rays, opts.image_width, opts.image_height))
+        cap = max(1, int(self.trail_steps))
+        old = self._trail
+        if old is not None and old["trail"].shape == (cap, slots) and old["trail"].device == dev:
+            trail, hops = old["trail"], old["hops"]     # reuse the allocation
+        else:
+            self._trail = None
+            trail = torch.empty((cap, slots), dtype=torch.int32, device=dev)
+            hops = torch.empty((slots,), dtype=torch.int32, device=dev)
+        opts.trail = trail.data_ptr()
+        opts.trail_hops = hops.data_ptr()
+        opts.trail_cap = cap
+        opts.trail_slots = slots
+        return trail, hops
+
     # -- trace_forward ---------------------------------------------------------------------------
     def trace_forward(self, points, attributes, point_adjacency, point_adjacency_offsets, rays,
                       start_point, depth_quantiles=None, weight_threshold=None,
@@ -252,6 +284,9 @@ class Pipeline:
             depth_indices = torch.zeros(batch + (nq,), dtype=torch.uint32, device=dev)
 
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
+        trail = None
+        if self.record_trail and num_rays > 0:
+            trail = self._new_trail(opts, num_rays, dev)
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_forward(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),
@@ -260,6 +295,15 @@ class Pipeline:
                 _ptr(depth_indices), _ptr(num_intersections), _ptr(contribution), C.byref(opts),
                 _stream_ptr(dev))
         _lib.check(rc)
+        if trail is not None:
+            foam = (points_c, attributes_c, adjacency_c, offsets_c)
+            self._trail = {
+                "key": self._trail_key(foam, rays_c, start_c, quantiles_c, settings),
+                "refs": foam + (rays_c, start_c, quantiles_c),   # keep the storages from being recycled
+                "trail": trail[0], "hops": trail[1], "cap": opts.trail_cap, "slots": opts.trail_slots,
+            }
+        else:
+            self._trail = None
 
         out = {"rgba": rgba}
         if quantiles_c is not None:
@@ -358,6 +402,13 @@ class Pipeline:
         ray_grad = torch.zeros_like(rays_c)
 
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
+        tr = self._trail
+        if tr is not None and tr["key"] == self._trail_key((points_c, attributes_c, adjacency_c, offsets_c),
+                                                            rays_c, start_c, quantiles_c, settings):
+            opts.trail = tr["trail"].data_ptr()
+            opts.trail_hops = tr["hops"].data_ptr()
+            opts.trail_cap = tr["cap"]
+            opts.trail_slots = tr["slots"]
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_backward(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),

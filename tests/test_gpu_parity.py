@@ -140,18 +140,31 @@ def _backward_case(foam_factory, d, seed, image, quantiles, with_error, n_points
     return fm, rays, starts, q, dg, g, err, fwd, ref
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("trail", ["rewalk", "replay", "short"])
 @pytest.mark.parametrize("d,image,quantiles,with_error", [
     (0, True, False, False), (1, False, True, True), (2, True, True, False), (2, False, False, True),
     (3, True, False, False), (3, False, True, True),
 ])
-def test_backward_parity(foam_factory, d, image, quantiles, with_error, mode):
+def test_backward_parity(foam_factory, d, image, quantiles, with_error, mode, trail):
+    """trail: 'rewalk' = backward re-scans every cell (no forward call on this pipeline);
+    'replay' = backward replays the hop trail recorded by trace_forward; 'short' = the trail holds
+    only 5 hops per ray, the rest is re-scanned."""
     fm, rays, starts, q, dg, g, err, fwd, ref = _backward_case(foam_factory, d, 20 + d, image, quantiles, with_error)
     pipe = _pipeline(d)
     pipe.backward_mode = mode
     p, a, adj, off = H.to_torch_foam(fm, DEV)
     t = lambda x: None if x is None else torch.from_numpy(x).to(DEV)
-    out = pipe.trace_backward(p, a, adj, off, t(rays), t(starts), t(fwd["rgba"]), t(g), t(q),
+    tr, ts, tq = t(rays), t(starts), t(q)
+    if trail == "rewalk":
+        pipe.record_trail = False
+    else:
+        if trail == "short":
+            pipe.trail_steps = 5
+        f = pipe.trace_forward(p, a, adj, off, tr, ts, depth_quantiles=tq)
+        np.testing.assert_array_equal(f["rgba"].cpu().numpy().view(np.uint32), fwd["rgba"].view(np.uint32))
+        assert pipe._trail is not None
+    out = pipe.trace_backward(p, a, adj, off, tr, ts, t(fwd["rgba"]), t(g), tq,
                               t(fwd.get("depth_indices")), t(dg), t(err))
     torch.cuda.synchronize()
     assert out["points_grad"].shape == (fm["points"].shape[0], 3)

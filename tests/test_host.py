@@ -26,7 +26,8 @@ def test_c_abi_library_exports_every_declared_symbol():
 
     declared = _declared_symbols()
     assert {"rf_trace_forward", "rf_trace_backward", "rf_trace_benchmark", "rf_prepare_foam",
-            "rf_build_adjacent_diff", "rf_workspace_bytes", "rf_last_error", "rf_attribute_dim"} <= declared
+            "rf_build_adjacent_diff", "rf_workspace_bytes", "rf_last_error", "rf_attribute_dim",
+            "rf_trail_slots"} <= declared
     assert declared == set(_lib.SYMBOLS), "ctypes table and include/radfoam_hip.h disagree"
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -41,7 +42,8 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Camera) == 4 * 12 + 4 + 4 * 3
     assert _lib.LaunchOpts.workspace.offset == 0 and _lib.LaunchOpts.workspace_bytes.offset == 8
     assert _lib.LaunchOpts.foam_prepared.offset == 16 and _lib.LaunchOpts.stats.offset == 32
-    assert ctypes.sizeof(_lib.LaunchOpts) == 40
+    assert _lib.LaunchOpts.trail.offset == 40 and _lib.LaunchOpts.trail_cap.offset == 56
+    assert ctypes.sizeof(_lib.LaunchOpts) == 64
 
 
 def test_host_only_entry_points():
