@@ -91,15 +91,17 @@ struct BwdParams {
     const uint32_t *trail;
     const uint32_t *trail_hops;
     uint32_t trail_cap, trail_slots;
+    unsigned long long *stats;   // optional scatter counters (experiments): [0] row flushes [1] values flushed
+                                 // [2] lane contributions that bypassed the block cache [3] cached lane contributions
 };
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 #ifndef RF_MAX_DISTINCT
-#define RF_MAX_DISTINCT 16
+#define RF_MAX_DISTINCT 24
 #endif
 #ifndef RF_STAGE_CAP
-#define RF_STAGE_CAP 400
+#define RF_STAGE_CAP 512
 #endif
 constexpr int kMaxDistinct = RF_MAX_DISTINCT;  // distinct cells per wave-step staged through LDS
 constexpr int kStageCap = RF_STAGE_CAP;        // fat entries of LDS per wave (16 B each)
@@ -152,24 +154,21 @@ __device__ __forceinline__ uint32_t stage_faces(const uint4 *faces, uint4 *lds, 
     uint32_t my = kNone;
     uint32_t used = 0;
     uint64_t todo = ballot(need);
-#pragma unroll
-    for (int it = 0; it < kMaxDistinct; ++it) {
-        if (todo != 0ull) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t b = readlane(nb, leader);
-            const uint32_t c = readlane(cnt, leader);
-            const bool mine = need && nb == b;
-            const uint64_t same = ballot(mine);
-            if (c <= 64u && used + c <= (uint32_t)kStageCap) {
-                if (lane < c) {
-                    // lane l copies entry b+l to lds[used + l]  (LDS address = M0 base + 16*lane)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(faces + b + lane), (lptr_t)(lds + used), 16, 0, 0);
-                }
-                if (mine) my = used;
-                used += c;
+    for (int it = 0; it < kMaxDistinct && todo != 0ull; ++it) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t b = readlane(nb, leader);
+        const uint32_t c = readlane(cnt, leader);
+        const bool mine = need && nb == b;
+        const uint64_t same = ballot(mine);
+        if (c <= 64u && used + c <= (uint32_t)kStageCap) {
+            if (lane < c) {
+                // lane l copies entry b+l to lds[used + l]  (LDS address = M0 base + 16*lane)
+                __builtin_amdgcn_global_load_lds((gptr_t)(faces + b + lane), (lptr_t)(lds + used), 16, 0, 0);
             }
-            todo &= ~same;
+            if (mine) my = used;
+            used += c;
         }
+        todo &= ~same;
     }
     return my;
 }
@@ -196,12 +195,37 @@ __device__ __forceinline__ void face_hit(uint2 e, float Px, float Py, float Pz, 
     t = dot3(vx, vy, vz, ox, oy, oz) / dp;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// n / d for two independent quotients with packed FMAs.  This is the instruction sequence hipcc
+// expands an IEEE fp32 divide into (v_rcp_f32, one Newton step on the reciprocal, two residual
+// corrections of the quotient), minus v_div_scale / v_div_fmas / v_div_fixup, which only act when
+// an operand or the quotient is subnormal, huge, zero, infinite or NaN.  For every other input
+// the result is bit-identical to '/'.  In the face scan the excluded cases are planes (almost)
+// parallel to the ray: the candidate then loses against any regular face exactly as the IEEE
+// quotient (inf or a huge number) would, or -- subnormal quotient -- yields a zero-length segment.
+__device__ __forceinline__ v2f div2(v2f n, v2f d) {
+    v2f y0;
+    y0.x = __builtin_amdgcn_rcpf(d.x);
+    y0.y = __builtin_amdgcn_rcpf(d.y);
+    const v2f one = {1.0f, 1.0f};
+    v2f e = fma2(-d, y0, one);
+    v2f y1 = fma2(e, y0, y0);
+    v2f q0 = n * y1;
+    v2f r0 = fma2(-d, q0, n);
+    v2f q1 = fma2(r0, y1, q0);
+    v2f r1 = fma2(-d, q1, n);
+    return fma2(r1, y1, q1);
+}
+
 // Nearest exit of the ray from the cell whose faces are fat entries [nb, nb+cnt); ascending
 // order, strict '<' (the first minimum wins, like the reference).  `my` != kNone: the list was
 // staged at lds[my..]; else it is read from global memory.  Four faces per iteration are
-// evaluated branch-free as independent chains (ILP; the IEEE divide is an 11-instruction
-// dependent sequence), the next four are fetched meanwhile.  Reads may run up to 7 entries
-// past the list: both the LDS stage and the table are padded.
+// evaluated branch-free, two at a time in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32: two faces per VALU slot), while the next four are fetched.  Reads may run up to
+// 7 entries past the list: both the LDS stage and the table are padded.
 template <bool FROM_LDS>
 __device__ __forceinline__ ScanResult scan_faces(const uint4 *src, uint32_t cnt, float Px, float Py,
                                                  float Pz, float Ox, float Oy, float Oz, float dx,
@@ -210,6 +234,10 @@ __device__ __forceinline__ ScanResult scan_faces(const uint4 *src, uint32_t cnt,
     r.t1 = __builtin_inff();
     r.k = kNone;
     r.w1 = 0u;
+    const v2f P2x = {Px, Px}, P2y = {Py, Py}, P2z = {Pz, Pz};
+    const v2f O2x = {Ox, Ox}, O2y = {Oy, Oy}, O2z = {Oz, Oz};
+    const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
+    const v2f half2 = {0.5f, 0.5f};
     uint2 e[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) e[j] = *reinterpret_cast<const uint2 *>(src + j);
@@ -219,17 +247,34 @@ __device__ __forceinline__ ScanResult scan_faces(const uint4 *src, uint32_t cnt,
         for (int j = 0; j < 4; ++j) nx[j] = *reinterpret_cast<const uint2 *>(src + k + 4 + j);
         float dp[4], t[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) face_hit(e[j], Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz, dp[j], t[j]);
+        for (int h = 0; h < 2; ++h) {
+            const uint2 ea = e[2 * h], eb = e[2 * h + 1];
+            const v2f ox = {half_lo(ea.x), half_lo(eb.x)};
+            const v2f oy = {half_hi(ea.x), half_hi(eb.x)};
+            const v2f oz = {half_lo(ea.y), half_lo(eb.y)};
+            // dp = fma(ox,dx, fma(oy,dy, oz*dz))
+            const v2f dpp = fma2(ox, d2x, fma2(oy, d2y, oz * d2z));
+            // v = (P + o/2) - O ; num = fma(vx,ox, fma(vy,oy, vz*oz))
+            const v2f vx = fma2(ox, half2, P2x) - O2x;
+            const v2f vy = fma2(oy, half2, P2y) - O2y;
+            const v2f vz = fma2(oz, half2, P2z) - O2z;
+            const v2f num = fma2(vx, ox, fma2(vy, oy, vz * oz));
+            const v2f q = div2(num, dpp);
+            dp[2 * h] = dpp.x;
+            dp[2 * h + 1] = dpp.y;
+            t[2 * h] = q.x;
+            t[2 * h + 1] = q.y;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bool better = (dp[j] > 0.0f) && (k + j < cnt) && (t[j] < r.t1);
             r.t1 = better ? t[j] : r.t1;
             r.k = better ? k + j : r.k;
-            r.w1 = better ? e[j].y : r.w1;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[j] = nx[j];
     }
+    if (r.k != kNone) r.w1 = reinterpret_cast<const uint2 *>(src + r.k)->y;
     return r;
 }
 
@@ -886,6 +931,12 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
     bool alive = map_ray(p.grid, ray);
     const FoamView &fv = p.foam;
     constexpr int NB = sh_dim(DEG);
+    // with a trail: this launch only handles the rays whose hops did not fit in it (the replay
+    // kernel did the others)
+    if (p.trail_hops) {
+        if (alive && p.trail_hops[blockIdx.x * (uint32_t)kBlock + threadIdx.x] <= p.trail_cap) alive = false;
+        if (__syncthreads_or(alive ? 1 : 0) == 0) return;
+    }
 
     BwdRay R;
     init_backward_ray(R);
@@ -957,8 +1008,8 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
 // Backward by replaying the trail trace_forward recorded for exactly these rays: hop i of a ray
 // went through fat face entry trail[i]; its t1 is recomputed with the same arithmetic (so it
 // is the same float), and no face list is scanned.  Entries, and the next cell's record, are
-// fetched two / one hops ahead.  A ray with more hops than the trail holds re-scans its cells
-// from global memory past that point.
+// fetched two / one hops ahead.  A ray with more hops than the trail holds is skipped here and
+// handled by a second launch of the re-walk kernel (backward_kernel), which takes only those.
 template <int DEG, bool HALF, int MODE>
 __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -975,9 +1026,10 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
     uint32_t cur = 0;
     uint32_t hops = 0;
     if (alive) {
-        load_backward_ray<DEG, HALF>(p, ray, R, cur);
         hops = p.trail_hops[slot];
+        if (hops > cap) alive = false;   // did not fit in the trail: left to the re-walk launch
     }
+    if (alive) load_backward_ray<DEG, HALF>(p, ray, R, cur);
     float sh[NB];
     sh_basis<DEG>(R.dx, R.dy, R.dz, sh);
     const uint32_t max_steps = p.settings.max_intersections;
@@ -989,11 +1041,8 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
     uint4 ent0 = make_uint4(0u, 0u, 0u, 0u), ent1 = make_uint4(0u, 0u, 0u, 0u);
     float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t e2 = 0;
-    uint32_t nb = 0, cnt = 0;   // face range of the current cell (needed past the trail only)
     if (alive) {
         head = fv.cells[cur];
-        nb = fv.offsets[cur];
-        cnt = fv.offsets[cur + 1] - nb;
         if (recorded > 0) ent0 = fv.faces[p.trail[slot]];
         if (recorded > 1) ent1 = fv.faces[p.trail[slots + slot]];
         if (recorded > 2) e2 = p.trail[2 * slots + slot];
@@ -1029,23 +1078,10 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float t1 = 0.0f;
         if (alive) {
-            if (i < recorded) {
-                ent = ent0;
-                nhead = q0;
-                float dp;
-                face_hit(make_uint2(ent.x, ent.y), head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
-            } else {
-                // past the recorded trail: scan this cell from global memory
-                ScanResult sr = scan_faces<false>(fv.faces + nb, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz,
-                                                  R.dx, R.dy, R.dz);
-                if (sr.k == kNone) {
-                    alive = false;
-                } else {
-                    ent = fv.faces[nb + sr.k];
-                    nhead = fv.cells[ent.z];
-                    t1 = sr.t1;
-                }
-            }
+            ent = ent0;
+            nhead = q0;
+            float dp;
+            face_hit(make_uint2(ent.x, ent.y), head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
         }
         if (alive) {
             if (t1 > R.t0) {
@@ -1053,8 +1089,6 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
             }
             R.t0 = __builtin_fmaxf(R.t0, t1);
             cur = ent.z;
-            nb = ent.w;
-            cnt = ent.y >> 16;
             head = nhead;
             i++;
         }
@@ -1077,7 +1111,7 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 // line), at a few 10^9 requests/s chip-wide -- far fewer than the (ray, step) contributions of a
 // frame.  The four waves of a block walk one 16x16 pixel tile, i.e. the same few hundred cells
 // within a few steps of each other, so their contributions are first summed in LDS:
-//   * a direct-mapped (two probes) table of kCacheRows rows keyed by cell id; a row holds the A
+//   * an open-addressing (kCacheProbes linear probes) table of kCacheRows rows keyed by cell id; a row holds the A
 //     attribute gradients of the cell followed by its 3 point-gradient components;
 //   * lanes add with LDS atomics (ds_add_f32); a lane whose key finds no free row adds straight
 //     to global memory instead;
@@ -1087,12 +1121,19 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 
 constexpr int kCacheRows = 256;
 constexpr int kCacheBits = 8;
-constexpr int kEpoch = 8;
+#ifndef RF_CACHE_PROBES
+#define RF_CACHE_PROBES 4
+#endif
+#ifndef RF_CACHE_EPOCH
+#define RF_CACHE_EPOCH 8
+#endif
+constexpr int kCacheProbes = RF_CACHE_PROBES;
+constexpr int kEpoch = RF_CACHE_EPOCH;
 
 __device__ __forceinline__ int cache_find(uint32_t *keys, uint32_t key) {
     const uint32_t h = (key * 2654435761u) >> (32 - kCacheBits);
 #pragma unroll
-    for (int probe = 0; probe < 2; ++probe) {
+    for (int probe = 0; probe < kCacheProbes; ++probe) {
         const uint32_t slot = (h + (uint32_t)probe) & (uint32_t)(kCacheRows - 1);
         const uint32_t old = atomicCAS(&keys[slot], kNone, key);
         if (old == kNone || old == key) return (int)slot;
@@ -1104,7 +1145,8 @@ __device__ __forceinline__ int cache_find(uint32_t *keys, uint32_t key) {
 // touch flag is clear; the flags of the others are cleared for the next epoch.
 template <int A>
 __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint32_t *touch, bool all,
-                                            float *attr_grad, float *points_grad) {
+                                            float *attr_grad, float *points_grad,
+                                            unsigned long long *g_dbg = nullptr) {
     constexpr int NVAL = A + 3;
     constexpr int STRIDE = NVAL | 1;
     const uint32_t half = threadIdx.x >> 5, col0 = threadIdx.x & 31u;
@@ -1113,10 +1155,16 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint32_
         if (key == kNone) continue;
         const bool evict = all || touch[r] == 0u;
         if (evict) {
+#ifdef RF_EXPERIMENT_STATS
+            if (col0 == 0u && g_dbg) atomicAdd(g_dbg + 0, 1ull);
+#endif
             for (uint32_t col = col0; col < (uint32_t)NVAL; col += 32u) {
                 float *cell = rows + r * STRIDE + col;
                 const float v = *cell;
                 if (v != 0.0f) {
+#ifdef RF_EXPERIMENT_STATS
+                    if (g_dbg) atomicAdd(g_dbg + 1, 1ull);
+#endif
                     *cell = 0.0f;
                     float *dst = (col < (uint32_t)A) ? attr_grad + (size_t)key * A + col
                                                       : points_grad + 3 * (size_t)key + (col - (uint32_t)A);
@@ -1130,8 +1178,40 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint32_
     }
 }
 
+// One stage of the in-register pre-reduction that precedes the LDS adds: lanes l and l^BIT that
+// both hold a contribution for the same key are merged into the lower lane; the upper lane drops
+// out (`act` cleared).  Fewer lanes then hit the same LDS address (ds_add_f32 serialises them).
+template <int BIT, int NV>
+__device__ __forceinline__ void absorb_stage(uint32_t lane, uint32_t key, bool &act, float (&v)[NV]) {
+    const uint32_t kp = xor_lane_u<BIT>(key);
+    const bool actp = xor_lane_u<BIT>(act ? 1u : 0u) != 0u;
+    const bool same = act && actp && kp == key;
+    if (ballot(same) == 0ull) return;
+    const bool upper = (lane & (uint32_t)BIT) != 0u;
+    const float m = (same && !upper) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = fma_(xor_lane_any<BIT>(v[i]), m, v[i]);
+    if (same && upper) act = false;
+}
+
+#ifndef RF_ABSORB_STAGES
+#define RF_ABSORB_STAGES 4
+#endif
+template <int NV>
+__device__ __forceinline__ void absorb_all(uint32_t lane, uint32_t key, bool &act, float (&v)[NV]) {
+    absorb_stage<1, NV>(lane, key, act, v);
+    absorb_stage<2, NV>(lane, key, act, v);
+    absorb_stage<4, NV>(lane, key, act, v);
+    if constexpr (RF_ABSORB_STAGES > 3) absorb_stage<8, NV>(lane, key, act, v);
+    if constexpr (RF_ABSORB_STAGES > 4) absorb_stage<16, NV>(lane, key, act, v);
+    if constexpr (RF_ABSORB_STAGES > 5) absorb_stage<32, NV>(lane, key, act, v);
+}
+
 template <int DEG, bool HALF>
-__global__ __launch_bounds__(kBlock) void backward_replay_cached_kernel(BwdParams p) {
+#ifndef RF_BWD_WAVES
+#define RF_BWD_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backward_replay_cached_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
     constexpr int A = 1 + 3 * NB;
     constexpr int NVAL = A + 3;
@@ -1158,9 +1238,10 @@ __global__ __launch_bounds__(kBlock) void backward_replay_cached_kernel(BwdParam
     uint32_t cur = 0;
     uint32_t hops = 0;
     if (alive) {
-        load_backward_ray<DEG, HALF>(p, ray, R, cur);
         hops = p.trail_hops[slot];
+        if (hops > cap) alive = false;   // did not fit in the trail: left to the re-walk launch
     }
+    if (alive) load_backward_ray<DEG, HALF>(p, ray, R, cur);
     float sh[NB];
     sh_basis<DEG>(R.dx, R.dy, R.dz, sh);
     const uint32_t max_steps = p.settings.max_intersections;
@@ -1170,11 +1251,8 @@ __global__ __launch_bounds__(kBlock) void backward_replay_cached_kernel(BwdParam
     uint4 ent0 = make_uint4(0u, 0u, 0u, 0u), ent1 = make_uint4(0u, 0u, 0u, 0u);
     float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t e2 = 0;
-    uint32_t nb = 0, cnt = 0;
     if (alive) {
         head = fv.cells[cur];
-        nb = fv.offsets[cur];
-        cnt = fv.offsets[cur + 1] - nb;
         if (recorded > 0) ent0 = fv.faces[p.trail[slot]];
         if (recorded > 1) ent1 = fv.faces[p.trail[slots + slot]];
         if (recorded > 2) e2 = p.trail[2 * slots + slot];
@@ -1206,22 +1284,10 @@ __global__ __launch_bounds__(kBlock) void backward_replay_cached_kernel(BwdParam
             float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             float t1 = 0.0f;
             if (alive) {
-                if (i < recorded) {
-                    ent = ent0;
-                    nhead = q0;
-                    float dp;
-                    face_hit(make_uint2(ent.x, ent.y), head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
-                } else {
-                    ScanResult sr = scan_faces<false>(fv.faces + nb, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz,
-                                                      R.dx, R.dy, R.dz);
-                    if (sr.k == kNone) {
-                        alive = false;
-                    } else {
-                        ent = fv.faces[nb + sr.k];
-                        nhead = fv.cells[ent.z];
-                        t1 = sr.t1;
-                    }
-                }
+                ent = ent0;
+                nhead = q0;
+                float dp;
+                face_hit(make_uint2(ent.x, ent.y), head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
             }
             if (alive) {
                 if (t1 > R.t0) {
@@ -1229,8 +1295,6 @@ __global__ __launch_bounds__(kBlock) void backward_replay_cached_kernel(BwdParam
                 }
                 R.t0 = __builtin_fmaxf(R.t0, t1);
                 cur = ent.z;
-                nb = ent.w;
-                cnt = ent.y >> 16;
                 head = nhead;
                 i++;
             }
@@ -1240,37 +1304,65 @@ __global__ __launch_bounds__(kBlock) void backward_replay_cached_kernel(BwdParam
             e2 = e3;
 
             // add this hop's gradients to the block cache (or straight to memory on a table conflict)
-            if (G.has) {
-                const int s_row = cache_find(s_keys, G.cur);
-                if (s_row >= 0) {
-                    s_touch[s_row] = 1u;
-                    float *dst = s_rows + s_row * STRIDE;
-                    if (G.row) {
+            {
+                const uint32_t lane = threadIdx.x & 63u;
+                // -- density gradient (every composited segment) and colour row (lit cells only)
+                bool act = G.has;
+                float dsv[1] = {G.dL_ds};
+                if (ballot(G.has && G.row) != 0ull) {
+                    float v[A];
 #pragma unroll
-                        for (int k = 0; k < 3 * NB; ++k) {
-                            float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
-                            atomicAdd(dst + k, sh[k / 3] * gc);
+                    for (int k = 0; k < 3 * NB; ++k) {
+                        float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
+                        v[k] = G.row ? sh[k / 3] * gc : 0.0f;
+                    }
+                    v[A - 1] = G.dL_ds;
+                    absorb_all<A>(lane, G.cur, act, v);
+                    if (act) {
+                        const int s_row = cache_find(s_keys, G.cur);
+                        float *dst = s_row >= 0 ? s_rows + s_row * STRIDE : p.attr_grad + (size_t)G.cur * A;
+                        if (s_row >= 0) {
+                            s_touch[s_row] = 1u;
+#pragma unroll
+                            for (int k = 0; k < A; ++k)
+                                if (v[k] != 0.0f) atomicAdd(dst + k, v[k]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < A; ++k)
+                                if (v[k] != 0.0f) grad_add(dst + k, v[k]);
                         }
                     }
-                    atomicAdd(dst + (A - 1), G.dL_ds);
-                } else {
-                    float *dst = p.attr_grad + (size_t)G.cur * A;
-                    if (G.row) add_row_per_lane<NB>(dst, sh, G.dLr, G.dLg, G.dLb);
-                    grad_add(dst + (A - 1), G.dL_ds);
+                } else if (ballot(G.has) != 0ull) {
+                    absorb_all<1>(lane, G.cur, act, dsv);
+                    if (act) {
+                        const int s_row = cache_find(s_keys, G.cur);
+                        if (s_row >= 0) {
+                            s_touch[s_row] = 1u;
+                            atomicAdd(s_rows + s_row * STRIDE + (A - 1), dsv[0]);
+                        } else {
+                            grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), dsv[0]);
+                        }
+                    }
                 }
-                if (G.pg_on) {
-                    const int s_pg = cache_find(s_keys, G.prev);
-                    if (s_pg >= 0) {
-                        s_touch[s_pg] = 1u;
-                        float *dst = s_rows + s_pg * STRIDE + A;
-                        atomicAdd(dst + 0, G.px);
-                        atomicAdd(dst + 1, G.py);
-                        atomicAdd(dst + 2, G.pz);
-                    } else {
-                        float *dst = p.points_grad + 3 * (size_t)G.prev;
-                        grad_add(dst + 0, G.px);
-                        grad_add(dst + 1, G.py);
-                        grad_add(dst + 2, G.pz);
+                // -- point gradient of the previous cell
+                if (ballot(G.has && G.pg_on) != 0ull) {
+                    bool pact = G.has && G.pg_on;
+                    float pv[3] = {G.px, G.py, G.pz};
+                    absorb_all<3>(lane, G.prev, pact, pv);
+                    if (pact) {
+                        const int s_pg = cache_find(s_keys, G.prev);
+                        if (s_pg >= 0) {
+                            s_touch[s_pg] = 1u;
+                            float *dst = s_rows + s_pg * STRIDE + A;
+                            atomicAdd(dst + 0, pv[0]);
+                            atomicAdd(dst + 1, pv[1]);
+                            atomicAdd(dst + 2, pv[2]);
+                        } else {
+                            float *dst = p.points_grad + 3 * (size_t)G.prev;
+                            grad_add(dst + 0, pv[0]);
+                            grad_add(dst + 1, pv[1]);
+                            grad_add(dst + 2, pv[2]);
+                        }
                     }
                 }
             }
@@ -1281,7 +1373,7 @@ __global__ __launch_bounds__(kBlock) void backward_replay_cached_kernel(BwdParam
         it++;
         if ((it & (uint32_t)(kEpoch - 1)) == 0u) {
             block_alive = __syncthreads_or(alive ? 1 : 0) != 0;
-            cache_flush<A>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad);
+            cache_flush<A>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad, p.stats);
             __syncthreads();
         }
     }
@@ -1461,6 +1553,11 @@ struct LaunchBackward {
                 hipLaunchKernelGGL((backward_replay_kernel<DEG, HALF, 2>), dim3(nb), dim3(kBlock), 0, stream, p);
             else
                 hipLaunchKernelGGL((backward_replay_cached_kernel<DEG, HALF>), dim3(nb), dim3(kBlock), 0, stream, p);
+            // rays that did not fit in the trail (blocks without any exit at once)
+            if (mode == 1)
+                hipLaunchKernelGGL((backward_kernel<DEG, HALF, 1>), dim3(nb), dim3(kBlock), 0, stream, p);
+            else
+                hipLaunchKernelGGL((backward_kernel<DEG, HALF, 2>), dim3(nb), dim3(kBlock), 0, stream, p);
         } else {
             if (mode == 1)
                 hipLaunchKernelGGL((backward_kernel<DEG, HALF, 1>), dim3(nb), dim3(kBlock), 0, stream, p);
@@ -1638,6 +1735,7 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     p.points_grad = points_grad;
     p.attr_grad = static_cast<float *>(attribute_grad);
     p.point_error = static_cast<float *>(point_error);
+    p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < grid_blocks(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: trail_slots smaller than rf_trail_slots()");

@@ -45,6 +45,31 @@ __device__ __forceinline__ float xor_lane(float x) {
     }
 }
 
+// value of lane (l ^ BIT) for any power-of-two BIT < 64
+template <int BIT>
+__device__ __forceinline__ float xor_lane_any(float x) {
+    if constexpr (BIT <= 8) {
+        return xor_lane<BIT>(x);
+    } else if constexpr (BIT == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x),
+                                                  false, false);
+        // r[0]: odd rows replaced by the even-row copy's data; r[1]: even rows replaced by odd rows' data
+        const bool odd_row = (lane_id() & 16u) != 0u;
+        return __builtin_bit_cast(float, (unsigned)(odd_row ? r[0] : r[1]));
+    } else {
+        static_assert(BIT == 32, "xor_lane_any: BIT must be a power of two below 64");
+        auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x),
+                                                  false, false);
+        const bool hi = (lane_id() & 32u) != 0u;
+        return __builtin_bit_cast(float, (unsigned)(hi ? r[0] : r[1]));
+    }
+}
+
+template <int BIT>
+__device__ __forceinline__ uint32_t xor_lane_u(uint32_t x) {
+    return __builtin_bit_cast(uint32_t, xor_lane_any<BIT>(__builtin_bit_cast(float, x)));
+}
+
 // a' + b' where the pair (a,b) is exchanged across lane bit 4 / bit 5:
 // result(lane) = (bit clear ? a : b)(lane) + (bit clear ? a : b)(lane ^ BIT)
 __device__ __forceinline__ float swap16_sum(float a, float b) {

@@ -218,6 +218,21 @@ class Pipeline:
                 self._cache.clear()
         return opts
 
+    def prepare_foam(self, points, attributes, point_adjacency, point_adjacency_offsets):
+        """Pack the foam now (rf_prepare_foam) so that the next trace_* call on the same tensors
+        finds it cached.  Optional: trace_forward / trace_backward pack on demand."""
+        points_c, attributes_c = points.contiguous(), attributes.contiguous()
+        adjacency_c, offsets_c = point_adjacency.contiguous(), point_adjacency_offsets.contiguous()
+        self._validate_scene_data(points, attributes, point_adjacency, point_adjacency_offsets)
+        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, ())
+        if not opts.foam_prepared:
+            with torch.cuda.device(points_c.device):
+                rc = self._lib.rf_prepare_foam(
+                    self._sh_degree, self._attr_type, points_c.size(0), _ptr(points_c), _ptr(attributes_c),
+                    adjacency_c.numel(), _ptr(adjacency_c), _ptr(offsets_c), None, opts.workspace,
+                    opts.workspace_bytes, _stream_ptr(points_c.device))
+            _lib.check(rc)
+
     # -- hop trail -------------------------------------------------------------------------------
     @staticmethod
     def _tkey(t):

@@ -6,6 +6,6 @@ for v in $VARIANTS; do
   python - "$v" <<'PY'
 import json,sys
 d=json.load(open('/tmp/o.json')); w=d['detail']['walk']
-print(sys.argv[1], 'Mrays/s', d['value'], 'fwd', d['detail']['forward_ms'], 'fwd_cached', d['detail']['forward_ms_packed_foam_cached'], 'bwd', d['detail']['backward_ms'], 'staged frac', round(w.get('lane_steps_staged_in_lds',0)/w['cells_scanned'],3), 'lane util', round(w['cells_scanned']/max(w.get('wave_steps',1),1)/64,3), 'wave_steps', w.get('wave_steps'))
+print(sys.argv[1], 'Mrays/s', d['value'], 'fwd', d['detail']['forward_ms'], 'pack', d['detail']['foam_pack_ms'], 'bwd', d['detail']['backward_ms'], 'staged frac', round(w.get('lane_steps_staged_in_lds',0)/w['cells_scanned'],3), 'lane util', round(w['cells_scanned']/max(w.get('wave_steps',1),1)/64,3), 'wave_steps', w.get('wave_steps'))
 PY
 done
