@@ -191,3 +191,32 @@ def test_foam_generator_contract():
     assert (fm["attributes"][r > 0.8, -1] == 0).all() and (fm["attributes"][r < 0.79, -1] > 0).all()
     again = foam.make_synthetic_foam(1500, 1, 2)
     assert np.array_equal(again["points"], fm["points"]) and np.array_equal(again["attributes"], fm["attributes"])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/radfoam_model"), reason="reference not on this box")
+def test_reference_python_callers_import_and_reach_this_boundary(monkeypatch):
+    """The reference's own radfoam_model/render.py and scene.py, unmodified, against `import radfoam`
+    from this repository: they import, and TraceRays.apply drives Pipeline.trace_forward with the
+    reference's argument pattern (rejected here only because the tensors are CPU tensors)."""
+    import sys
+    import types
+
+    import radfoam
+
+    monkeypatch.syspath_prepend("/root/reference")
+    ply = types.ModuleType("plyfile")   # scene.py imports plyfile for save_ply only
+    ply.PlyData = ply.PlyElement = object
+    monkeypatch.setitem(sys.modules, "plyfile", ply)
+    for name in [m for m in sys.modules if m.startswith("radfoam_model")]:
+        monkeypatch.delitem(sys.modules, name)
+    import importlib
+
+    render = importlib.import_module("radfoam_model.render")
+    scene = importlib.import_module("radfoam_model.scene")
+    assert scene.radfoam is radfoam and hasattr(scene, "RadFoamScene")
+    pipe = radfoam.create_pipeline(1)
+    kw = _cpu_inputs(a=13)
+    with pytest.raises(RuntimeError, match="points must be on CUDA device"):
+        render.TraceRays.apply(pipe, kw["points"].requires_grad_(), kw["attributes"].requires_grad_(),
+                               kw["point_adjacency"], kw["point_adjacency_offsets"], kw["rays"],
+                               kw["start_point"], None, False)
