@@ -198,6 +198,18 @@ def main():
             dist.destroy_process_group()
         return
 
+    # HBM traffic per launch from the PMC passes recorded under profiles/ (separate rocprofv3 runs;
+    # cannot be read from inside this process).  Only quoted when it was measured on this workload.
+    traffic = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        w = tj["workload"]
+        if (w["num_points"], w["sh_degree"], w["width"], w["height"], w["seed"]) == (
+                args.points, args.sh_degree, args.width, args.height, args.seed):
+            traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
+    except (OSError, KeyError, ValueError):
+        pass
+
     dom_is_bwd = (not args.forward_only) and bwd_ms >= fwd_ms
     dom_bytes, dom_ms = (bytes_bwd, bwd_ms) if dom_is_bwd else (bytes_fwd, fwd_ms)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
@@ -231,7 +243,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic.get("backward_replay_cached_kernel" if dom_is_bwd else "forward_kernel"),
             "algorithmic_bytes_per_launch": int(dom_bytes),
             "avg_launch_ms": round(dom_ms, 4),
         },
