@@ -1141,14 +1141,28 @@ __device__ __forceinline__ int cache_find(uint32_t *keys, uint32_t key) {
     return -1;
 }
 
+// LDS row layout of the block cache (floats): [0, 3B) colour gradients, zero padding up to SHP
+// (a multiple of 4), then the density gradient at SHP and the 3 point-gradient components at
+// SHP+1..SHP+3.  The colour part is updated by read-modify-write under a per-row lock (whole
+// float4s), the last float4 only ever by LDS atomics, so the two never touch the same 16 bytes.
+template <int NB>
+struct CacheLayout {
+    static constexpr int NCOEF = 3 * NB;
+    static constexpr int SHP = (NCOEF + 3) & ~3;
+    static constexpr int COL_DS = SHP;
+    static constexpr int COL_PG = SHP + 1;
+    static constexpr int NCOL = SHP + 4;
+    static constexpr int STRIDE = NCOL + 4;   // 16-B aligned rows whose starts rotate through the banks
+};
+
 // Flush rows to global memory (whole block, between barriers).  all == false: only rows whose
 // touch flag is clear; the flags of the others are cleared for the next epoch.
-template <int A>
+template <int NB>
 __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint32_t *touch, bool all,
                                             float *attr_grad, float *points_grad,
                                             unsigned long long *g_dbg = nullptr) {
-    constexpr int NVAL = A + 3;
-    constexpr int STRIDE = NVAL | 1;
+    using L = CacheLayout<NB>;
+    constexpr int A = 1 + 3 * NB;
     const uint32_t half = threadIdx.x >> 5, col0 = threadIdx.x & 31u;
     for (uint32_t r = half; r < (uint32_t)kCacheRows; r += (uint32_t)(kBlock / 32)) {
         const uint32_t key = keys[r];
@@ -1158,16 +1172,19 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint32_
 #ifdef RF_EXPERIMENT_STATS
             if (col0 == 0u && g_dbg) atomicAdd(g_dbg + 0, 1ull);
 #endif
-            for (uint32_t col = col0; col < (uint32_t)NVAL; col += 32u) {
-                float *cell = rows + r * STRIDE + col;
+            for (uint32_t col = col0; col < (uint32_t)L::NCOL; col += 32u) {
+                float *cell = rows + r * L::STRIDE + col;
                 const float v = *cell;
                 if (v != 0.0f) {
 #ifdef RF_EXPERIMENT_STATS
                     if (g_dbg) atomicAdd(g_dbg + 1, 1ull);
 #endif
                     *cell = 0.0f;
-                    float *dst = (col < (uint32_t)A) ? attr_grad + (size_t)key * A + col
-                                                      : points_grad + 3 * (size_t)key + (col - (uint32_t)A);
+                    float *dst;
+                    if (col < (uint32_t)L::NCOEF) dst = attr_grad + (size_t)key * A + col;
+                    else if (col == (uint32_t)L::COL_DS) dst = attr_grad + (size_t)key * A + (A - 1);
+                    else if (col >= (uint32_t)L::COL_PG) dst = points_grad + 3 * (size_t)key + (col - (uint32_t)L::COL_PG);
+                    else continue;   // padding
                     grad_add(dst, v);
                 }
             }
@@ -1214,15 +1231,17 @@ template <int DEG, bool HALF>
 __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backward_replay_cached_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
     constexpr int A = 1 + 3 * NB;
-    constexpr int NVAL = A + 3;
-    constexpr int STRIDE = NVAL | 1;
-    __shared__ float s_rows[kCacheRows * STRIDE];
+    using L = CacheLayout<NB>;
+    constexpr int STRIDE = L::STRIDE;
+    __shared__ __attribute__((aligned(16))) float s_rows[kCacheRows * STRIDE];
     __shared__ uint32_t s_keys[kCacheRows];
     __shared__ uint32_t s_touch[kCacheRows];
+    __shared__ uint32_t s_lock[kCacheRows];
     for (uint32_t i = threadIdx.x; i < (uint32_t)(kCacheRows * STRIDE); i += kBlock) s_rows[i] = 0.0f;
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCacheRows; i += kBlock) {
         s_keys[i] = kNone;
         s_touch[i] = 0u;
+        s_lock[i] = 0u;
     }
     __syncthreads();
 
@@ -1318,27 +1337,61 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
                     }
                     v[A - 1] = G.dL_ds;
                     absorb_all<A>(lane, G.cur, act, v);
-                    if (act) {
-                        const int s_row = cache_find(s_keys, G.cur);
-                        float *dst = s_row >= 0 ? s_rows + s_row * STRIDE : p.attr_grad + (size_t)G.cur * A;
-                        if (s_row >= 0) {
-                            s_touch[s_row] = 1u;
+                    // rows whose colour part is not all zero need the locked read-modify-write
+                    bool colour = false;
 #pragma unroll
-                            for (int k = 0; k < A; ++k)
-                                if (v[k] != 0.0f) atomicAdd(dst + k, v[k]);
-                        } else {
+                    for (int k = 0; k < 3 * NB; ++k) colour = colour || (v[k] != 0.0f);
+                    const int s_row = act ? cache_find(s_keys, G.cur) : -1;
+                    if (act && s_row < 0) {
+                        float *dst = p.attr_grad + (size_t)G.cur * A;
 #pragma unroll
-                            for (int k = 0; k < A; ++k)
-                                if (v[k] != 0.0f) grad_add(dst + k, v[k]);
+                        for (int k = 0; k < A; ++k)
+                            if (v[k] != 0.0f) grad_add(dst + k, v[k]);
+                    }
+                    if (act && s_row >= 0) {
+                        s_touch[s_row] = 1u;
+                        atomicAdd(s_rows + s_row * STRIDE + L::COL_DS, v[A - 1]);
+                    }
+#ifdef RF_X_NO_LITADD
+                    if (act && s_row >= 0 && v[0] == 123.456f) s_rows[s_row * STRIDE] = v[1] + v[5];
+#else
+                    bool todo = act && s_row >= 0 && colour;
+                    float vc[L::SHP];
+#pragma unroll
+                    for (int k = 0; k < L::SHP; ++k) vc[k] = (k < 3 * NB) ? v[k < 3 * NB ? k : 0] : 0.0f;
+                    while (ballot(todo) != 0ull) {
+                        if (todo) {
+                            uint32_t *lock = s_lock + s_row;
+                            uint32_t expected = 0u;
+                            if (__hip_atomic_compare_exchange_strong(lock, &expected, 1u, __ATOMIC_ACQUIRE,
+                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                float4 *r4 = reinterpret_cast<float4 *>(s_rows + s_row * STRIDE);
+#pragma unroll
+                                for (int j = 0; j < L::SHP / 4; ++j) {
+                                    float4 x = r4[j];
+                                    x.x += vc[4 * j + 0];
+                                    x.y += vc[4 * j + 1];
+                                    x.z += vc[4 * j + 2];
+                                    x.w += vc[4 * j + 3];
+                                    r4[j] = x;
+                                }
+                                __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                todo = false;
+                            }
                         }
                     }
+#endif
                 } else if (ballot(G.has) != 0ull) {
                     absorb_all<1>(lane, G.cur, act, dsv);
                     if (act) {
                         const int s_row = cache_find(s_keys, G.cur);
                         if (s_row >= 0) {
                             s_touch[s_row] = 1u;
-                            atomicAdd(s_rows + s_row * STRIDE + (A - 1), dsv[0]);
+#ifdef RF_X_NO_DENSADD
+                            if (dsv[0] == 123.456f) s_rows[s_row * STRIDE] = dsv[0];
+#else
+                            atomicAdd(s_rows + s_row * STRIDE + L::COL_DS, dsv[0]);
+#endif
                         } else {
                             grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), dsv[0]);
                         }
@@ -1353,7 +1406,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
                         const int s_pg = cache_find(s_keys, G.prev);
                         if (s_pg >= 0) {
                             s_touch[s_pg] = 1u;
-                            float *dst = s_rows + s_pg * STRIDE + A;
+                            float *dst = s_rows + s_pg * STRIDE + L::COL_PG;
                             atomicAdd(dst + 0, pv[0]);
                             atomicAdd(dst + 1, pv[1]);
                             atomicAdd(dst + 2, pv[2]);
@@ -1373,7 +1426,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
         it++;
         if ((it & (uint32_t)(kEpoch - 1)) == 0u) {
             block_alive = __syncthreads_or(alive ? 1 : 0) != 0;
-            cache_flush<A>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad, p.stats);
+            cache_flush<NB>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad, p.stats);
             __syncthreads();
         }
     }
