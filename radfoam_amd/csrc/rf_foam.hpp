@@ -5,16 +5,18 @@
 // (offsets[i], offsets[i+1] -> face table -> adjacency[e] -> points[j]); rf_prepare_foam re-lays
 // the foam so that a hop costs ONE dependent round trip:
 //
-//   workspace = [ float4 cells[N] | uint4 faces[E + 32] | SH rows[N][sh_stride] (optional) ]
+//   workspace = [ float4 cells[N] | uint2 geo[E + 32] | uint2 link[E] | SH rows[N][sh_stride] (optional) ]
 //
 //   cells[i]   {x, y, z, density}                                           16 B, 16-B aligned
-//   faces[e]   "fat" face entry, 16 B, one per CSR entry, a cell's faces contiguous:
+//   geo[e]     8 B per CSR entry, a cell's faces contiguous (what the scan streams):
 //                .x = half(dx) | half(dy) << 16      (dx,dy,dz) = points[adj[e]] - points[owner(e)],
 //                .y = half(dz) | nbr_faces << 16       fp16 RNE == the reference's half4 table
-//                .z = adj[e]                           (pipeline.cu:546-568)
-//                .w = offsets[adj[e]]                  the neighbour's first face
-//              so the winning face of a scan already names the next cell AND where its faces
-//              are: the next cell's face list, cell record and SH row can all be requested at once.
+//                                                      (pipeline.cu:546-568) with the neighbour's
+//                                                      face count in the unused w slot
+//   link[e]    {adj[e], offsets[adj[e]]}: the neighbour and its first face -- read once per hop,
+//              for the winning face only.  Together with nbr_faces the winning face already names
+//              the next cell AND where its faces are: the next cell's face list, cell record and
+//              SH row can all be requested at once.
 //   SH rows    the 3B colour coefficients of a cell, 16-B aligned rows of sh_stride scalars;
 //              present only when the caller's row pitch (A scalars) is not 16-B aligned
 //              (d=1,3); otherwise the kernels read the caller's attribute rows in place.
@@ -32,7 +34,8 @@ constexpr uint32_t kFacePad = 32;  // entries; same slack the reference allocate
 
 struct FoamLayout {
     size_t cells_off;
-    size_t faces_off;
+    size_t geo_off;
+    size_t link_off;
     size_t sh_off;       // 0 when rows are read in place
     uint32_t sh_stride;  // scalars per SH row as the kernels see it
     bool sh_repacked;
@@ -56,8 +59,10 @@ inline FoamLayout foam_layout(uint32_t num_points, uint32_t adj_size, int sh_deg
     L.sh_stride = in_place ? A : (uint32_t)align_up(ncoef, 4);
     L.cells_off = 0;
     size_t off = align_up((size_t)num_points * 16, 256);
-    L.faces_off = off;
-    off = align_up(off + ((size_t)adj_size + kFacePad) * 16, 256);
+    L.geo_off = off;
+    off = align_up(off + ((size_t)adj_size + kFacePad) * 8, 256);
+    L.link_off = off;
+    off = align_up(off + (size_t)adj_size * 8, 256);
     if (L.sh_repacked) {
         L.sh_off = off;
         off = align_up(off + (size_t)num_points * L.sh_stride * (attr_half ? 2 : 4), 256);

@@ -1,18 +1,22 @@
 // rf_kernels.hip -- gfx950 (MI355X) kernels of the Voronoi-foam ray tracer + the C-ABI.
 //
 // One lane walks one ray; a wave64 owns an 8x8 pixel tile when the rays form an image, so its
-// lanes sit in the same few cells.  Per step the wave
-//   1. stages the face lists of its (up to kMaxDistinct) distinct current cells into LDS with
-//      one coalesced global->LDS DMA each (lanes in other cells fall back to their own loads),
-//   2. every lane scans its cell's faces out of LDS (broadcast reads) for the nearest exit,
-//   3. the winning "fat" face entry names the next cell AND its face range, so the next stage,
-//      the next cell record and the colour row are requested together: one dependent round
-//      trip per hop instead of the reference's four,
-//   4. composites the segment (forward) / accumulates gradients (backward) while those loads fly.
-// Backward pre-reduces gradient rows across the lanes that sit in the same cell with a
-// transposing DPP butterfly and issues ONE coalesced atomic row per distinct cell.
-// Blocks are handed to XCDs in contiguous chunks of the tile order so each XCD's private L2
-// sees one band of the image (= one slab of the foam).
+// lanes sit in neighbouring cells and their gathers hit the same few cache lines.  Per step a lane
+//   1. scans its cell's faces for the nearest exit: four faces per iteration, branch-free, two
+//      faces per VALU slot in packed fp32, the next four entries prefetched meanwhile;
+//   2. reads the link of the winning face: it names the next cell AND its face range, so the next
+//      cell record, its face list and the colour row are requested together -- one dependent
+//      round trip per hop instead of the reference's four;
+//   3. composites the segment (forward) / accumulates gradients (backward).
+// Forward records the face of every hop (the "trail"); backward replays it instead of scanning
+// again, and sums gradient rows in a block-level LDS write-combining cache before they go to
+// global atomics.  Blocks are handed to XCDs in contiguous chunks of the tile order so each
+// XCD's private L2 sees one band of the image (= one slab of the foam).
+//
+// Tried and measured out: staging the wave's distinct cells' face lists in
+// LDS (global_load_lds DMA + ballot/readlane dedupe).  The lanes of a tile sit in 16-24
+// different cells at any step, so the dedupe loop cost more than the L1-served gathers it
+// replaced (forward 10.8 ms staged vs 8.8 ms direct on the 2M-point foam).
 //
 // Kernels (reference counterparts in src/tracing/pipeline.cu):
 //   prepare_foam_kernel    prefetch_adjacent_diff_kernel :546-568  (+ cell/face packing)
@@ -38,7 +42,8 @@ namespace rf {
 
 struct FoamView {
     const float4 *cells;        // {x, y, z, density}
-    const uint4 *faces;         // fat face entries (rf_foam.hpp)
+    const uint2 *geo;           // per face: fp16 offset to the neighbour | neighbour's face count
+    const uint2 *link;          // per face: {neighbour index, neighbour's first face}
     const uint32_t *offsets;    // caller's CSR offsets (entry cell's face range)
     const void *sh;             // SH rows, sh_stride scalars apart
     uint32_t sh_stride;
@@ -96,15 +101,6 @@ struct BwdParams {
 };
 
 constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / 64;
-#ifndef RF_MAX_DISTINCT
-#define RF_MAX_DISTINCT 24
-#endif
-#ifndef RF_STAGE_CAP
-#define RF_STAGE_CAP 512
-#endif
-constexpr int kMaxDistinct = RF_MAX_DISTINCT;  // distinct cells per wave-step staged through LDS
-constexpr int kStageCap = RF_STAGE_CAP;        // fat entries of LDS per wave (16 B each)
 
 // ------------------------------------------------------------------------------------------
 // block -> tile, lane -> ray
@@ -137,43 +133,6 @@ inline uint32_t grid_blocks(const RayGrid &g) {
     if (g.img_w) return ((g.img_w + 15u) >> 4) * ((g.img_h + 15u) >> 4);
     return (g.num_rays + (uint32_t)kBlock - 1u) / (uint32_t)kBlock;
 }
-
-// ------------------------------------------------------------------------------------------
-// staging of face lists: global -> LDS, one DMA per distinct cell of the wave
-
-typedef __attribute__((address_space(1))) const void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
-
-// Every lane calls this (convergent).  `need` lanes want faces [nb, nb+cnt) of the fat table.
-// Returns the lane's entry offset into `lds`, or kNone if its cell was not staged (more than
-// kMaxDistinct distinct cells in the wave, a list longer than 64, or LDS space exhausted): such
-// lanes read the table from global memory instead.  The DMA is asynchronous: the caller must
-// execute wait_staged() before reading `lds`.
-__device__ __forceinline__ uint32_t stage_faces(const uint4 *faces, uint4 *lds, uint32_t lane,
-                                                bool need, uint32_t nb, uint32_t cnt) {
-    uint32_t my = kNone;
-    uint32_t used = 0;
-    uint64_t todo = ballot(need);
-    for (int it = 0; it < kMaxDistinct && todo != 0ull; ++it) {
-        const int leader = __builtin_ctzll(todo);
-        const uint32_t b = readlane(nb, leader);
-        const uint32_t c = readlane(cnt, leader);
-        const bool mine = need && nb == b;
-        const uint64_t same = ballot(mine);
-        if (c <= 64u && used + c <= (uint32_t)kStageCap) {
-            if (lane < c) {
-                // lane l copies entry b+l to lds[used + l]  (LDS address = M0 base + 16*lane)
-                __builtin_amdgcn_global_load_lds((gptr_t)(faces + b + lane), (lptr_t)(lds + used), 16, 0, 0);
-            }
-            if (mine) my = used;
-            used += c;
-        }
-        todo &= ~same;
-    }
-    return my;
-}
-
-__device__ __forceinline__ void wait_staged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------
 // the per-cell face scan                         reference: trace<>, tracing_utils.cuh:27-67
@@ -220,14 +179,17 @@ __device__ __forceinline__ v2f div2(v2f n, v2f d) {
     return fma2(r1, y1, q1);
 }
 
-// Nearest exit of the ray from the cell whose faces are fat entries [nb, nb+cnt); ascending
-// order, strict '<' (the first minimum wins, like the reference).  `my` != kNone: the list was
-// staged at lds[my..]; else it is read from global memory.  Four faces per iteration are
-// evaluated branch-free, two at a time in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 /
-// v_pk_add_f32: two faces per VALU slot), while the next four are fetched.  Reads may run up to
-// 7 entries past the list: both the LDS stage and the table are padded.
-template <bool FROM_LDS>
-__device__ __forceinline__ ScanResult scan_faces(const uint4 *src, uint32_t cnt, float Px, float Py,
+struct __attribute__((aligned(8))) GeoPair {
+    uint2 a, b;
+};
+
+// Nearest exit of the ray from the cell whose faces are geo entries src[0..cnt); ascending order,
+// strict '<' (the first minimum wins, like the reference).  Four faces per iteration are evaluated
+// branch-free, two at a time in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two faces
+// per VALU slot), while the next four are fetched (two 16-byte gathers; a list starts on an 8-byte
+// boundary, which this hardware serves -- scripts/probe/unaligned.hip).  Reads may run up to 7
+// entries past the list: the table is padded with kFacePad zero entries.
+__device__ __forceinline__ ScanResult scan_faces(const uint2 *src, uint32_t cnt, float Px, float Py,
                                                  float Pz, float Ox, float Oy, float Oz, float dx,
                                                  float dy, float dz) {
     ScanResult r;
@@ -238,13 +200,12 @@ __device__ __forceinline__ ScanResult scan_faces(const uint4 *src, uint32_t cnt,
     const v2f O2x = {Ox, Ox}, O2y = {Oy, Oy}, O2z = {Oz, Oz};
     const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
     const v2f half2 = {0.5f, 0.5f};
-    uint2 e[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) e[j] = *reinterpret_cast<const uint2 *>(src + j);
+    GeoPair e0 = *reinterpret_cast<const GeoPair *>(src);
+    GeoPair e1 = *reinterpret_cast<const GeoPair *>(src + 2);
     for (uint32_t k = 0; k < cnt; k += 4) {
-        uint2 nx[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) nx[j] = *reinterpret_cast<const uint2 *>(src + k + 4 + j);
+        const GeoPair n0 = *reinterpret_cast<const GeoPair *>(src + k + 4);
+        const GeoPair n1 = *reinterpret_cast<const GeoPair *>(src + k + 6);
+        const uint2 e[4] = {e0.a, e0.b, e1.a, e1.b};
         float dp[4], t[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -270,27 +231,19 @@ __device__ __forceinline__ ScanResult scan_faces(const uint4 *src, uint32_t cnt,
             bool better = (dp[j] > 0.0f) && (k + j < cnt) && (t[j] < r.t1);
             r.t1 = better ? t[j] : r.t1;
             r.k = better ? k + j : r.k;
+            r.w1 = better ? e[j].y : r.w1;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = nx[j];
+        e0 = n0;
+        e1 = n1;
     }
-    if (r.k != kNone) r.w1 = reinterpret_cast<const uint2 *>(src + r.k)->y;
     return r;
 }
 
-__device__ __forceinline__ ScanResult scan_cell(const uint4 *faces, const uint4 *lds, uint32_t my,
-                                                uint32_t nb, uint32_t cnt, float Px, float Py,
-                                                float Pz, float Ox, float Oy, float Oz, float dx,
-                                                float dy, float dz) {
-    if (my != kNone) return scan_faces<true>(lds + my, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
-    return scan_faces<false>(faces + nb, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
-}
-
-// {neighbour index, neighbour's first face} of entry k
-__device__ __forceinline__ uint2 face_link(const uint4 *faces, const uint4 *lds, uint32_t my,
-                                           uint32_t nb, uint32_t k) {
-    if (my != kNone) return *(reinterpret_cast<const uint2 *>(lds + my + k) + 1);
-    return *(reinterpret_cast<const uint2 *>(faces + nb + k) + 1);
+// fat view of face entry e: {geo.x, geo.y, neighbour index, neighbour's first face}
+__device__ __forceinline__ uint4 load_face(const FoamView &fv, uint32_t e) {
+    const uint2 g = fv.geo[e];
+    const uint2 l = fv.link[e];
+    return make_uint4(g.x, g.y, l.x, l.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -393,13 +346,10 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 // Control flow: every lane keeps an `alive` flag and the wave iterates while any lane is alive
 // (no per-lane `break` out of nested conditionals).  hipcc 7.2 was observed to miscompile the
 // natural `for(;;){...break...}` form of this loop (the next cell's face range was dropped on
-// the path through the compositing block); the flag form is also what wave-cooperative
-// staging needs (all lanes must reach stage_faces together).
+// the path through the compositing block).
 
 template <int DEG, bool HALF, bool BENCH>
 __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
-    __shared__ uint4 s_faces[kWaves * kStageCap + 8];
-    uint4 *lds = s_faces + (threadIdx.x >> 6) * kStageCap;
     const uint32_t lane = threadIdx.x & 63u;
 
     uint32_t ray;
@@ -451,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
     const float thr = p.settings.weight_threshold;
     const uint32_t max_steps = p.settings.max_intersections;
 
-    unsigned long long st_cells = 0, st_faces = 0, st_hops = 0, st_seg = 0, st_lit = 0, st_staged = 0;
+    unsigned long long st_cells = 0, st_faces = 0, st_hops = 0, st_seg = 0, st_lit = 0;
     const bool want_stats = !BENCH && p.stats != nullptr;
 
     float t0 = 0.0f;
@@ -463,8 +413,6 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
         cnt = fv.offsets[cur + 1] - nb;
         head = fv.cells[cur];
     }
-    uint32_t my = stage_faces(fv.faces, lds, lane, alive, nb, cnt);
-
     uint32_t wave_steps = 0;
     uint32_t hops = 0;
     const uint32_t slot = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
@@ -474,24 +422,22 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
             n++;
             if (n > max_steps) alive = false;
         }
-        wait_staged();
         ScanResult sr;
         sr.t1 = __builtin_inff();
         sr.k = kNone;
         sr.w1 = 0u;
         if (alive) {
-            sr = scan_cell(fv.faces, lds, my, nb, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
+            sr = scan_faces(fv.geo + nb, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
             if (want_stats) {
                 st_cells++;
                 st_faces += cnt;
-                st_staged += (my != kNone) ? 1u : 0u;
             }
             if (sr.k == kNone) alive = false;
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (alive) {
-            uint2 link = face_link(fv.faces, lds, my, nb, sr.k);
+            const uint2 link = fv.link[nb + sr.k];
             nxt = link.x;
             nnb = link.y;
             ncnt = sr.w1 >> 16;
@@ -504,9 +450,6 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
                 }
             }
         }
-        // every LDS read of this step has been consumed: re-stage for the next step now, so the
-        // DMA flies while the segment is composited
-        const uint32_t nmy = stage_faces(fv.faces, lds, lane, alive, nnb, ncnt);
         if (alive) {
             const float t1 = sr.t1;
             if (want_stats) st_hops++;
@@ -544,10 +487,8 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
             head = nhead;
             nb = nnb;
             cnt = ncnt;
-            my = nmy;
         }
     }
-    wait_staged();  // no DMA may be in flight into this wave's LDS when the block retires
 
     if constexpr (!BENCH) {
         if (p.trail) p.trail_hops[slot] = valid ? hops : 0u;
@@ -576,7 +517,6 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
             atomicAdd(p.stats + 2, st_hops);
             atomicAdd(p.stats + 3, st_seg);
             atomicAdd(p.stats + 4, st_lit);
-            atomicAdd(p.stats + 5, st_staged);
             if (lane == 0) atomicAdd(p.stats + 6, (unsigned long long)wave_steps);
         }
     }
@@ -923,8 +863,6 @@ __device__ __forceinline__ void scatter_pending(const BwdParams &p, uint32_t lan
 // Backward by re-walking (no trail available): same scan as forward.
 template <int DEG, bool HALF, int MODE>
 __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
-    __shared__ uint4 s_faces[kWaves * kStageCap + 8];
-    uint4 *lds = s_faces + (threadIdx.x >> 6) * kStageCap;
     const uint32_t lane = threadIdx.x & 63u;
 
     uint32_t ray;
@@ -954,12 +892,9 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
         cnt = fv.offsets[cur + 1] - nb;
         head = fv.cells[cur];
     }
-    uint32_t my = stage_faces(fv.faces, lds, lane, alive, nb, cnt);
-
     // Gradient contributions of the step just finished are scattered at the top of the NEXT
-    // iteration, right after the wait for the staged faces: the atomics then complete under the
-    // long face scan instead of sitting in front of the next wait (memory operations retire in
-    // order, so an atomic issued after the stage DMA would otherwise delay it).
+    // iteration: the atomics then complete under the long face scan (memory operations retire in
+    // order, so a load issued after an atomic cannot complete before it).
     StepGrad G;
     clear_step(G);
 
@@ -968,26 +903,24 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
             n++;
             if (n > max_steps) alive = false;
         }
-        wait_staged();
         scatter_pending<DEG, MODE>(p, lane, sh, G);
         ScanResult sr;
         sr.t1 = __builtin_inff();
         sr.k = kNone;
         sr.w1 = 0u;
         if (alive) {
-            sr = scan_cell(fv.faces, lds, my, nb, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
+            sr = scan_faces(fv.geo + nb, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
             if (sr.k == kNone) alive = false;
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (alive) {
-            uint2 link = face_link(fv.faces, lds, my, nb, sr.k);
+            const uint2 link = fv.link[nb + sr.k];
             nxt = link.x;
             nnb = link.y;
             ncnt = sr.w1 >> 16;
             nhead = fv.cells[nxt];
         }
-        const uint32_t nmy = stage_faces(fv.faces, lds, lane, alive, nnb, ncnt);
         if (alive) {
             const float t1 = sr.t1;
             if (t1 > R.t0) {
@@ -998,10 +931,8 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
             head = nhead;
             nb = nnb;
             cnt = ncnt;
-            my = nmy;
         }
     }
-    wait_staged();
     scatter_pending<DEG, MODE>(p, lane, sh, G);
 }
 
@@ -1043,8 +974,8 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
     uint32_t e2 = 0;
     if (alive) {
         head = fv.cells[cur];
-        if (recorded > 0) ent0 = fv.faces[p.trail[slot]];
-        if (recorded > 1) ent1 = fv.faces[p.trail[slots + slot]];
+        if (recorded > 0) ent0 = load_face(fv, p.trail[slot]);
+        if (recorded > 1) ent1 = load_face(fv, p.trail[slots + slot]);
         if (recorded > 2) e2 = p.trail[2 * slots + slot];
         if (recorded > 0) q0 = fv.cells[ent0.z];
     }
@@ -1070,7 +1001,7 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
         uint32_t e3 = 0;
         if (alive) {
             if (i + 1 < recorded) q1 = fv.cells[ent1.z];
-            if (i + 2 < recorded) ent2 = fv.faces[e2];
+            if (i + 2 < recorded) ent2 = load_face(fv, e2);
             if (i + 3 < recorded) e3 = p.trail[(size_t)(i + 3) * slots + slot];
         }
         // (B) this hop
@@ -1272,8 +1203,8 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
     uint32_t e2 = 0;
     if (alive) {
         head = fv.cells[cur];
-        if (recorded > 0) ent0 = fv.faces[p.trail[slot]];
-        if (recorded > 1) ent1 = fv.faces[p.trail[slots + slot]];
+        if (recorded > 0) ent0 = load_face(fv, p.trail[slot]);
+        if (recorded > 1) ent1 = load_face(fv, p.trail[slots + slot]);
         if (recorded > 2) e2 = p.trail[2 * slots + slot];
         if (recorded > 0) q0 = fv.cells[ent0.z];
     }
@@ -1296,7 +1227,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
             uint32_t e3 = 0;
             if (alive) {
                 if (i + 1 < recorded) q1 = fv.cells[ent1.z];
-                if (i + 2 < recorded) ent2 = fv.faces[e2];
+                if (i + 2 < recorded) ent2 = load_face(fv, e2);
                 if (i + 3 < recorded) e3 = p.trail[(size_t)(i + 3) * slots + slot];
             }
             uint4 ent = make_uint4(0u, 0u, 0u, 0u);
@@ -1441,13 +1372,15 @@ __device__ __forceinline__ uint2 pack_diff(float dx, float dy, float dz) {
     return make_uint2(lo, hi);
 }
 
-// cells[i] = {x,y,z,density}; faces[e] = fat entry (rf_foam.hpp).  ext_diff != nullptr: take the
-// half offsets from the caller's half4 table instead of recomputing them (trace_benchmark).
+// cells[i] = {x,y,z,density}; geo[e] / link[e] = the face tables (rf_foam.hpp).  ext_diff !=
+// nullptr: take the half offsets from the caller's half4 table instead of recomputing them
+// (trace_benchmark).
 template <bool HALF>
 __global__ __launch_bounds__(256) void prepare_foam_kernel(
     const float *__restrict__ points, const void *__restrict__ attributes, uint32_t attr_dim,
     uint32_t num_points, const uint32_t *__restrict__ adj, const uint32_t *__restrict__ offsets,
-    const uint2 *__restrict__ ext_diff, float4 *__restrict__ cells, uint4 *__restrict__ faces) {
+    const uint2 *__restrict__ ext_diff, float4 *__restrict__ cells, uint2 *__restrict__ geo,
+    uint2 *__restrict__ link) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_points) return;
     float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
@@ -1465,7 +1398,8 @@ __global__ __launch_bounds__(256) void prepare_foam_kernel(
             d = pack_diff(qx - px, qy - py, qz - pz);
         }
         uint32_t qb = offsets[q], qe = offsets[q + 1];
-        faces[f] = make_uint4(d.x, d.y | ((qe - qb) << 16), q, qb);
+        geo[f] = make_uint2(d.x, d.y | ((qe - qb) << 16));
+        link[f] = make_uint2(q, qb);
     }
 }
 
@@ -1524,7 +1458,8 @@ static FoamView make_view(const FoamLayout &L, void *ws, const void *attributes,
     FoamView v;
     char *base = static_cast<char *>(ws);
     v.cells = reinterpret_cast<const float4 *>(base + L.cells_off);
-    v.faces = reinterpret_cast<const uint4 *>(base + L.faces_off);
+    v.geo = reinterpret_cast<const uint2 *>(base + L.geo_off);
+    v.link = reinterpret_cast<const uint2 *>(base + L.link_off);
     v.offsets = offsets;
     v.sh = L.sh_repacked ? static_cast<const void *>(base + L.sh_off) : attributes;
     v.sh_stride = L.sh_stride;
@@ -1541,17 +1476,18 @@ static int prepare_impl(int sh_degree, int attr_type, uint32_t num_points, const
     if (num_points == 0) return RF_OK;
     char *base = static_cast<char *>(ws);
     float4 *cells = reinterpret_cast<float4 *>(base + L.cells_off);
-    uint4 *faces = reinterpret_cast<uint4 *>(base + L.faces_off);
+    uint2 *geo = reinterpret_cast<uint2 *>(base + L.geo_off);
+    uint2 *link = reinterpret_cast<uint2 *>(base + L.link_off);
     const uint32_t A = attribute_dim(sh_degree);
     dim3 grid((num_points + 255u) / 256u), block(256);
     if (half)
         hipLaunchKernelGGL(prepare_foam_kernel<true>, grid, block, 0, stream, points, attributes, A, num_points,
-                           adj, offsets, static_cast<const uint2 *>(ext_diff), cells, faces);
+                           adj, offsets, static_cast<const uint2 *>(ext_diff), cells, geo, link);
     else
         hipLaunchKernelGGL(prepare_foam_kernel<false>, grid, block, 0, stream, points, attributes, A, num_points,
-                           adj, offsets, static_cast<const uint2 *>(ext_diff), cells, faces);
+                           adj, offsets, static_cast<const uint2 *>(ext_diff), cells, geo, link);
     // zero the padding so over-reads past the last cell see well-defined (never selected) entries
-    (void)hipMemsetAsync(faces + adj_size, 0, (size_t)kFacePad * 16, stream);
+    (void)hipMemsetAsync(geo + adj_size, 0, (size_t)kFacePad * 8, stream);
     if (L.sh_repacked) {
         size_t total = (size_t)num_points * L.sh_stride;
         dim3 g2((unsigned)((total + 255) / 256));
