@@ -348,7 +348,7 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 // natural `for(;;){...break...}` form of this loop (the next cell's face range was dropped on
 // the path through the compositing block).
 
-template <int DEG, bool HALF, bool BENCH>
+template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS>
 __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
     const uint32_t lane = threadIdx.x & 63u;
 
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
 
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f;
     uint32_t qi = 0;
-    const uint32_t nq = BENCH ? 0u : p.nq;
+    const uint32_t nq = QUANT ? p.nq : 0u;
     const float *qp = nullptr;
     float cq = 0.0f;
     if (nq && alive) {
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
     const uint32_t max_steps = p.settings.max_intersections;
 
     unsigned long long st_cells = 0, st_faces = 0, st_hops = 0, st_seg = 0, st_lit = 0;
-    const bool want_stats = !BENCH && p.stats != nullptr;
+    constexpr bool want_stats = STATS;
 
     float t0 = 0.0f;
     uint32_t n = 0;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
                 Cg = fma_(w, g, Cg);
                 Cb = fma_(w, b, Cb);
                 float Tn = T * (1.0f - alpha);
-                if constexpr (!BENCH) {
+                if constexpr (QUANT) {
                     while (qi < nq && Tn < cq) {
                         p.qdepth[(size_t)ray * nq + qi] = t0 + log_(T / cq) / s;
                         p.qidx[(size_t)ray * nq + qi] = cur;
@@ -1372,32 +1372,50 @@ __device__ __forceinline__ uint2 pack_diff(float dx, float dy, float dz) {
     return make_uint2(lo, hi);
 }
 
-// cells[i] = {x,y,z,density}; geo[e] / link[e] = the face tables (rf_foam.hpp).  ext_diff !=
-// nullptr: take the half offsets from the caller's half4 table instead of recomputing them
-// (trace_benchmark).
+// cells[i] = {x,y,z,density}; geo[e] / link[e] = the face tables (rf_foam.hpp).  A wave owns 64
+// consecutive cells and streams their (contiguous) faces with one lane per face, so adjacency reads
+// and table writes are coalesced; the owner of a face is found by binary search in the wave's 65
+// CSR offsets (LDS).  ext_diff != nullptr: take the half offsets from the caller's half4 table
+// instead of recomputing them (trace_benchmark).
 template <bool HALF>
 __global__ __launch_bounds__(256) void prepare_foam_kernel(
     const float *__restrict__ points, const void *__restrict__ attributes, uint32_t attr_dim,
     uint32_t num_points, const uint32_t *__restrict__ adj, const uint32_t *__restrict__ offsets,
     const uint2 *__restrict__ ext_diff, float4 *__restrict__ cells, uint2 *__restrict__ geo,
     uint2 *__restrict__ link) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= num_points) return;
-    float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
-    uint32_t b = offsets[i], e = offsets[i + 1];
-    float s = load_attr_scalar<HALF>(attributes, (size_t)i * attr_dim + attr_dim - 1);
-    cells[i] = make_float4(px, py, pz, s);
-    for (uint32_t f = b; f < e; ++f) {
-        uint32_t q = adj[f];
+    __shared__ uint32_t s_off[4][66];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t c0 = (blockIdx.x * 4u + wave) * 64u;
+    if (c0 >= num_points) return;
+    const uint32_t ncells = (num_points - c0 < 64u) ? num_points - c0 : 64u;
+    uint32_t *off = s_off[wave];
+    if (lane <= ncells) off[lane] = offsets[c0 + lane];
+    if (lane == 0u) off[ncells] = offsets[c0 + ncells];
+    if (lane < ncells) {
+        const uint32_t i = c0 + lane;
+        float s = load_attr_scalar<HALF>(attributes, (size_t)i * attr_dim + attr_dim - 1);
+        cells[i] = make_float4(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2], s);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t f_begin = off[0], f_end = off[ncells];
+    for (uint32_t f = f_begin + lane; f < f_end; f += 64u) {
+        uint32_t lo = 0, hi = ncells;   // owner: last cell whose first face is <= f
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] <= f) lo = mid; else hi = mid;
+        }
+        const uint32_t i = c0 + lo;
+        const uint32_t q = adj[f];
         uint2 d;
         if (ext_diff) {
             d = ext_diff[f];
             d.y &= 0xFFFFu;
         } else {
-            float qx = points[3 * (size_t)q], qy = points[3 * (size_t)q + 1], qz = points[3 * (size_t)q + 2];
+            const float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
+            const float qx = points[3 * (size_t)q], qy = points[3 * (size_t)q + 1], qz = points[3 * (size_t)q + 2];
             d = pack_diff(qx - px, qy - py, qz - pz);
         }
-        uint32_t qb = offsets[q], qe = offsets[q + 1];
+        const uint32_t qb = offsets[q], qe = offsets[q + 1];
         geo[f] = make_uint2(d.x, d.y | ((qe - qb) << 16));
         link[f] = make_uint2(q, qb);
     }
@@ -1479,7 +1497,7 @@ static int prepare_impl(int sh_degree, int attr_type, uint32_t num_points, const
     uint2 *geo = reinterpret_cast<uint2 *>(base + L.geo_off);
     uint2 *link = reinterpret_cast<uint2 *>(base + L.link_off);
     const uint32_t A = attribute_dim(sh_degree);
-    dim3 grid((num_points + 255u) / 256u), block(256);
+    dim3 grid((num_points + 255u) / 256u), block(256);   // 4 waves x 64 cells per block
     if (half)
         hipLaunchKernelGGL(prepare_foam_kernel<true>, grid, block, 0, stream, points, attributes, A, num_points,
                            adj, offsets, static_cast<const uint2 *>(ext_diff), cells, geo, link);
@@ -1523,9 +1541,13 @@ struct LaunchForward {
         uint32_t nb = grid_blocks(p.grid);
         if (nb == 0) return RF_OK;
         if (bench)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, true>), dim3(nb), dim3(kBlock), 0, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+        else if (p.stats)
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, true>), dim3(nb), dim3(kBlock), 0, stream, p);
+        else if (p.nq)
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false>), dim3(nb), dim3(kBlock), 0, stream, p);
         else
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
         return check_launch(bench ? "rf_trace_benchmark" : "rf_trace_forward");
     }
 };
