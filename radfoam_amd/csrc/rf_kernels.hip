@@ -734,12 +734,12 @@ __device__ __forceinline__ void init_backward_ray(BwdRay &R) {
 
 // The backward functor for the segment [t0,t1] of cell `cur` (reference: pipeline.cu:180-331).
 // Returns false when the ray terminates (transmittance below the threshold).
-template <int DEG, bool HALF>
+template <int DEG, bool HALF, bool QUANT = true>
 __device__ __forceinline__ bool backward_segment(const BwdParams &p, BwdRay &R, const float (&sh)[sh_dim(DEG)],
                                                  uint32_t cur, float4 head, float4 nhead, float t1,
                                                  StepGrad &G) {
     const FoamView &fv = p.foam;
-    const uint32_t nq = p.nq;
+    const uint32_t nq = QUANT ? p.nq : 0u;
     const float t0 = R.t0;
     float s = head.w;
     float r = 0.0f, g = 0.0f, b = 0.0f;
@@ -768,17 +768,19 @@ __device__ __forceinline__ bool backward_segment(const BwdParams &p, BwdRay &R, 
     float dL_dt0 = 0.0f;
 
     float Tn = R.T * (1.0f - alpha);
-    while (R.qi < nq && Tn < R.cq) {
-        float gi = R.dgp[R.qi] / s;
-        dL_dt0 = dL_dt0 + gi;
-        dL_ds = dL_ds + ((-gi) * log_(R.T / R.cq)) / s;
-        R.cdg = R.cdg - gi;
-        R.qi++;
-        if (R.qi < nq) R.cq = R.qp[R.qi];
-    }
-    if (R.qi < nq) {
-        dL_ds = fma_(-dt, R.cdg, dL_ds);
-        dL_ddt = fma_(-s, R.cdg, dL_ddt);
+    if constexpr (QUANT) {
+        while (R.qi < nq && Tn < R.cq) {
+            float gi = R.dgp[R.qi] / s;
+            dL_dt0 = dL_dt0 + gi;
+            dL_ds = dL_ds + ((-gi) * log_(R.T / R.cq)) / s;
+            R.cdg = R.cdg - gi;
+            R.qi++;
+            if (R.qi < nq) R.cq = R.qp[R.qi];
+        }
+        if (R.qi < nq) {
+            dL_ds = fma_(-dt, R.cdg, dL_ds);
+            dL_ddt = fma_(-s, R.cdg, dL_ddt);
+        }
     }
     dL_dt0 = dL_dt0 + (-dL_ddt);
     float dL_dt1 = dL_ddt;
@@ -1155,7 +1157,7 @@ __device__ __forceinline__ void absorb_all(uint32_t lane, uint32_t key, bool &ac
     if constexpr (RF_ABSORB_STAGES > 5) absorb_stage<32, NV>(lane, key, act, v);
 }
 
-template <int DEG, bool HALF>
+template <int DEG, bool HALF, bool QUANT>
 #ifndef RF_BWD_WAVES
 #define RF_BWD_WAVES 3
 #endif
@@ -1241,7 +1243,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
             }
             if (alive) {
                 if (t1 > R.t0) {
-                    if (!backward_segment<DEG, HALF>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
+                    if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
                 }
                 R.t0 = __builtin_fmaxf(R.t0, t1);
                 cur = ent.z;
@@ -1287,9 +1289,6 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
                     if (act && s_row >= 0 && v[0] == 123.456f) s_rows[s_row * STRIDE] = v[1] + v[5];
 #else
                     bool todo = act && s_row >= 0 && colour;
-                    float vc[L::SHP];
-#pragma unroll
-                    for (int k = 0; k < L::SHP; ++k) vc[k] = (k < 3 * NB) ? v[k < 3 * NB ? k : 0] : 0.0f;
                     while (ballot(todo) != 0ull) {
                         if (todo) {
                             uint32_t *lock = s_lock + s_row;
@@ -1300,10 +1299,10 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
 #pragma unroll
                                 for (int j = 0; j < L::SHP / 4; ++j) {
                                     float4 x = r4[j];
-                                    x.x += vc[4 * j + 0];
-                                    x.y += vc[4 * j + 1];
-                                    x.z += vc[4 * j + 2];
-                                    x.w += vc[4 * j + 3];
+                                    x.x += (4 * j + 0 < 3 * NB) ? v[(4 * j + 0) % A] : 0.0f;
+                                    x.y += (4 * j + 1 < 3 * NB) ? v[(4 * j + 1) % A] : 0.0f;
+                                    x.z += (4 * j + 2 < 3 * NB) ? v[(4 * j + 2) % A] : 0.0f;
+                                    x.w += (4 * j + 3 < 3 * NB) ? v[(4 * j + 3) % A] : 0.0f;
                                     r4[j] = x;
                                 }
                                 __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1562,8 +1561,10 @@ struct LaunchBackward {
                 hipLaunchKernelGGL((backward_replay_kernel<DEG, HALF, 1>), dim3(nb), dim3(kBlock), 0, stream, p);
             else if (mode == 2)
                 hipLaunchKernelGGL((backward_replay_kernel<DEG, HALF, 2>), dim3(nb), dim3(kBlock), 0, stream, p);
+            else if (p.nq)
+                hipLaunchKernelGGL((backward_replay_cached_kernel<DEG, HALF, true>), dim3(nb), dim3(kBlock), 0, stream, p);
             else
-                hipLaunchKernelGGL((backward_replay_cached_kernel<DEG, HALF>), dim3(nb), dim3(kBlock), 0, stream, p);
+                hipLaunchKernelGGL((backward_replay_cached_kernel<DEG, HALF, false>), dim3(nb), dim3(kBlock), 0, stream, p);
             // rays that did not fit in the trail (blocks without any exit at once)
             if (mode == 1)
                 hipLaunchKernelGGL((backward_kernel<DEG, HALF, 1>), dim3(nb), dim3(kBlock), 0, stream, p);
