@@ -238,7 +238,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "backward_kernel" if dom_is_bwd else "forward_kernel",
+            "kernel": "backward_replay_cached_kernel" if dom_is_bwd else "forward_kernel",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
