@@ -453,14 +453,16 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
         if (alive) {
             const float t1 = sr.t1;
             if (want_stats) st_hops++;
-            if (t1 > t0) {
+            if (want_stats && t1 > t0) {
+                st_seg++;
+                st_lit += (head.w > 1e-6f) ? 1u : 0u;
+            }
+            // A segment through a cell of density exactly 0 changes nothing (alpha = 1 - exp(-0) = 0,
+            // weight 0, transmittance unchanged): skipped -- a wave in empty space skips the block.
+            if (t1 > t0 && head.w != 0.0f) {
                 float s = head.w;
                 float r = 0.0f, g = 0.0f, b = 0.0f;
                 if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
-                if (want_stats) {
-                    st_seg++;
-                    st_lit += (s > 1e-6f) ? 1u : 0u;
-                }
                 float dt = __builtin_fmaxf(t1 - t0, 0.0f);
                 float alpha = 1.0f - exp_(-s * dt);
                 float w = T * alpha;
