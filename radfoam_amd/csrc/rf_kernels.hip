@@ -759,9 +759,11 @@ __device__ __forceinline__ bool backward_segment(const BwdParams &p, BwdRay &R, 
 
     float dLr = R.gr * w, dLg = R.gg * w, dLb = R.gb * w;
     float den = R.T * ((1.0f - alpha) + 1e-6f);
-    float dfr = r - (R.outr - R.Cr) / den;
-    float dfg = g - (R.outg - R.Cg) / den;
-    float dfb = b - (R.outb - R.Cb) / den;
+    float rr, rg, rb;
+    div3(R.outr - R.Cr, R.outg - R.Cg, R.outb - R.Cb, den, rr, rg, rb);
+    float dfr = r - rr;
+    float dfg = g - rg;
+    float dfb = b - rb;
     float dL_da = R.T * dot3(dfr, dfg, dfb, R.gr, R.gg, R.gb);
     dL_da = dL_da + ((1.0f - R.outa) * R.ga) / ((1.0f - alpha) + 1e-6f);
 
@@ -787,25 +789,30 @@ __device__ __forceinline__ bool backward_segment(const BwdParams &p, BwdRay &R, 
     dL_dt0 = dL_dt0 + (-dL_ddt);
     float dL_dt1 = dL_ddt;
 
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;  // dt0_dprev
-    if (R.prev != kNone)
-        bisector_grad(R.ppx, R.ppy, R.ppz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ax, ay, az);
-    float bx, by, bz;                        // dt1_dcurrent
-    bisector_grad(head.x, head.y, head.z, nhead.x, nhead.y, nhead.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, bx, by, bz);
-    float ex, ey, ez;                        // dt0_dcurrent (vs prev, or vs origin on the first segment)
-    bisector_grad(head.x, head.y, head.z, R.ppx, R.ppy, R.ppz, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ex, ey, ez);
-    float fx, fy, fz;                        // dt1_dnext
-    bisector_grad(nhead.x, nhead.y, nhead.z, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, fx, fy, fz);
+    // The four bisector gradients only enter through dL_dt0 / dL_dt1; both are exactly zero in a
+    // cell of density 0 (83 % of the segments of the benchmark scene), where the block is skipped.
+    // (Differs from the reference only if a bisector gradient is non-finite there: 0 * inf.)
+    if (dL_dt0 != 0.0f || dL_dt1 != 0.0f) {
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;  // dt0_dprev
+        if (R.prev != kNone)
+            bisector_grad(R.ppx, R.ppy, R.ppz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ax, ay, az);
+        float bx, by, bz;                        // dt1_dcurrent
+        bisector_grad(head.x, head.y, head.z, nhead.x, nhead.y, nhead.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, bx, by, bz);
+        float ex, ey, ez;                        // dt0_dcurrent (vs prev, or vs origin on the first segment)
+        bisector_grad(head.x, head.y, head.z, R.ppx, R.ppy, R.ppz, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ex, ey, ez);
+        float fx, fy, fz;                        // dt1_dnext
+        bisector_grad(nhead.x, nhead.y, nhead.z, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, fx, fy, fz);
 
-    R.pgx = fma_(dL_dt0, ax, R.pgx);
-    R.pgy = fma_(dL_dt0, ay, R.pgy);
-    R.pgz = fma_(dL_dt0, az, R.pgz);
-    R.cgx = R.cgx + fma_(dL_dt0, ex, dL_dt1 * bx);
-    R.cgy = R.cgy + fma_(dL_dt0, ey, dL_dt1 * by);
-    R.cgz = R.cgz + fma_(dL_dt0, ez, dL_dt1 * bz);
-    R.ngx = fma_(dL_dt1, fx, R.ngx);
-    R.ngy = fma_(dL_dt1, fy, R.ngy);
-    R.ngz = fma_(dL_dt1, fz, R.ngz);
+        R.pgx = fma_(dL_dt0, ax, R.pgx);
+        R.pgy = fma_(dL_dt0, ay, R.pgy);
+        R.pgz = fma_(dL_dt0, az, R.pgz);
+        R.cgx = R.cgx + fma_(dL_dt0, ex, dL_dt1 * bx);
+        R.cgy = R.cgy + fma_(dL_dt0, ey, dL_dt1 * by);
+        R.cgz = R.cgz + fma_(dL_dt0, ez, dL_dt1 * bz);
+        R.ngx = fma_(dL_dt1, fx, R.ngx);
+        R.ngy = fma_(dL_dt1, fy, R.ngy);
+        R.ngz = fma_(dL_dt1, fz, R.ngz);
+    }
 
     // what the reference adds with atomics at this point (pipeline.cu:305-328): prev_point_grad ->
     // points_grad[prev]; the SH row and dL/ds -> attr_grad[cur].  Exact zeros are not added.

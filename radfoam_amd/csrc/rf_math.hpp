@@ -123,6 +123,20 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&sh)[
     }
 }
 
+// (nx, ny, nz) / den with one shared reciprocal: the instruction sequence hipcc expands each IEEE
+// fp32 divide into (v_rcp_f32, one Newton step on the reciprocal, two residual corrections of the
+// quotient) without v_div_scale / v_div_fmas / v_div_fixup, which only act when an operand or the
+// quotient is subnormal, huge, zero, infinite or NaN.  Bit-identical to three '/' otherwise.
+__device__ __forceinline__ void div3(float nx, float ny, float nz, float den, float &qx, float &qy, float &qz) {
+    float y = __builtin_amdgcn_rcpf(den);
+    float e = fma_(-den, y, 1.0f);
+    y = fma_(e, y, y);
+    float q, r;
+    q = nx * y; r = fma_(-den, q, nx); q = fma_(r, y, q); r = fma_(-den, q, nx); qx = fma_(r, y, q);
+    q = ny * y; r = fma_(-den, q, ny); q = fma_(r, y, q); r = fma_(-den, q, ny); qy = fma_(r, y, q);
+    q = nz * y; r = fma_(-den, q, nz); q = fma_(r, y, q); r = fma_(-den, q, nz); qz = fma_(r, y, q);
+}
+
 // d(t)/d(primal) of the ray/bisector(primal,opposite) hit; reference: cell_intersection_grad,
 // src/tracing/tracing_utils.cuh:91-103 (uses the fp32 points, not the fp16 face table).
 __device__ __forceinline__ void bisector_grad(float px, float py, float pz, float qx, float qy,
@@ -135,9 +149,7 @@ __device__ __forceinline__ void bisector_grad(float px, float py, float pz, floa
     float num = dot3(vx, vy, vz, fnx, fny, fnz);
     float dp = dot3(fnx, fny, fnz, dx, dy, dz);
     float den = dp * dp;
-    gx = fma_(num, dx, dp * (ox - px)) / den;
-    gy = fma_(num, dy, dp * (oy - py)) / den;
-    gz = fma_(num, dz, dp * (oz - pz)) / den;
+    div3(fma_(num, dx, dp * (ox - px)), fma_(num, dy, dp * (oy - py)), fma_(num, dz, dp * (oz - pz)), den, gx, gy, gz);
 }
 
 }  // namespace rf
