@@ -3,26 +3,28 @@
 // The caller's tensors are AoS as the reference API dictates (points[N][3], attributes[N][A],
 // CSR offsets[N+1], adjacency[E]).  A hop of the reference walk chases four dependent pointers
 // (offsets[i], offsets[i+1] -> face table -> adjacency[e] -> points[j]); rf_prepare_foam re-lays
-// the foam so that a hop costs ONE dependent round trip:
+// the foam so that a hop costs ONE dependent round trip and the face scan no unpacking:
 //
-//   workspace = [ float4 cells[N] | uint2 geo[E + 32] | uint2 link[E] | SH rows[N][sh_stride] (optional) ]
+//   workspace = [ float4 cells[N] | half geo[3 * EB] | Link link[EB] | uint32 poff[N+1] |
+//                 uint32 scan scratch | SH rows[N][sh_stride] (optional) ]
+//
+//   Every cell's face list is padded to a multiple of 4 entries; poff[i] is the first (padded)
+//   entry of cell i and poff[N] = E' <= EB = E + 3N the padded total.  Entries past a cell's real
+//   faces are all-zero (a zero offset is never an exit candidate: o.d = 0).
 //
 //   cells[i]   {x, y, z, density}                                           16 B, 16-B aligned
-//   geo[e]     8 B per CSR entry, a cell's faces contiguous (what the scan streams):
-//                .x = half(dx) | half(dy) << 16      (dx,dy,dz) = points[adj[e]] - points[owner(e)],
-//                .y = half(dz) | nbr_faces << 16       fp16 RNE == the reference's half4 table
-//                                                      (pipeline.cu:546-568) with the neighbour's
-//                                                      face count in the unused w slot
-//   link[e]    {adj[e], offsets[adj[e]]}: the neighbour and its first face -- read once per hop,
-//              for the winning face only.  Together with nbr_faces the winning face already names
-//              the next cell AND where its faces are: the next cell's face list, cell record and
-//              SH row can all be requested at once.
+//   geo        blocks of 4 consecutive entries, 24 B per block, components planar inside a block:
+//                half x[4], y[4], z[4]   with (x,y,z)[e] = points[adj[e]] - points[owner(e)]
+//              rounded to fp16 (RNE): exactly the values of the reference's half4 table
+//              (pipeline.cu:546-568), 6 B per face instead of 8.  An iteration of the scan reads
+//              a block with one 16-B and one 8-B load; each dword unpacks into an adjacent register
+//              pair, the operand of one packed-fp32 instruction (two faces per VALU slot).
+//   link[e]    {adj[e], poff[adj[e]], padded face count of adj[e]}, 12 B: the neighbour, where its
+//              faces start and how many -- read once per hop, for the winning face only; the next
+//              cell's face list, cell record and SH row can then all be requested at once.
 //   SH rows    the 3B colour coefficients of a cell, 16-B aligned rows of sh_stride scalars;
 //              present only when the caller's row pitch (A scalars) is not 16-B aligned
 //              (d=1,3); otherwise the kernels read the caller's attribute rows in place.
-//
-// nbr_faces is 16 bits: cells with more than 65535 Delaunay neighbours are not supported
-// (rf_prepare_foam does not check; random and trained foams have < 100).
 #pragma once
 
 #include <stddef.h>
@@ -30,12 +32,22 @@
 
 namespace rf {
 
-constexpr uint32_t kFacePad = 32;  // entries; same slack the reference allocates (pipeline.cu:613)
+constexpr uint32_t kFacePad = 32;     // entries of zero slack behind the last list (scan prefetch)
+constexpr uint32_t kScanChunk = 1024;  // cells per block of the padded-offset prefix sum
+
+struct Link {
+    uint32_t nbr;    // neighbour cell
+    uint32_t first;  // its first (padded) face entry
+    uint32_t count;  // its padded face count
+};
 
 struct FoamLayout {
     size_t cells_off;
     size_t geo_off;
     size_t link_off;
+    size_t poff_off;
+    size_t scan_off;     // per-chunk sums of the prefix sum
+    size_t max_entries;  // EB: upper bound of the padded entry count
     size_t sh_off;       // 0 when rows are read in place
     uint32_t sh_stride;  // scalars per SH row as the kernels see it
     bool sh_repacked;
@@ -59,10 +71,15 @@ inline FoamLayout foam_layout(uint32_t num_points, uint32_t adj_size, int sh_deg
     L.sh_stride = in_place ? A : (uint32_t)align_up(ncoef, 4);
     L.cells_off = 0;
     size_t off = align_up((size_t)num_points * 16, 256);
+    L.max_entries = align_up((size_t)adj_size + 3 * (size_t)num_points, 4);
     L.geo_off = off;
-    off = align_up(off + ((size_t)adj_size + kFacePad) * 8, 256);
+    off = align_up(off + (L.max_entries + kFacePad) * 6, 256);
     L.link_off = off;
-    off = align_up(off + (size_t)adj_size * 8, 256);
+    off = align_up(off + L.max_entries * 12, 256);
+    L.poff_off = off;
+    off = align_up(off + ((size_t)num_points + 1) * 4, 256);
+    L.scan_off = off;
+    off = align_up(off + ((size_t)num_points / kScanChunk + 2) * 4, 256);
     if (L.sh_repacked) {
         L.sh_off = off;
         off = align_up(off + (size_t)num_points * L.sh_stride * (attr_half ? 2 : 4), 256);

@@ -2,8 +2,9 @@
 //
 // One lane walks one ray; a wave64 owns an 8x8 pixel tile when the rays form an image, so its
 // lanes sit in neighbouring cells and their gathers hit the same few cache lines.  Per step a lane
-//   1. scans its cell's faces for the nearest exit: four faces per iteration, branch-free, two
-//      faces per VALU slot in packed fp32, the next four entries prefetched meanwhile;
+//   1. scans its cell's faces for the nearest exit: four faces per iteration (a 24-byte block of
+//      planar fp16 offsets, lists padded to a multiple of four), branch-free, two faces per VALU
+//      slot in packed fp32;
 //   2. reads the link of the winning face: it names the next cell AND its face range, so the next
 //      cell record, its face list and the colour row are requested together -- one dependent
 //      round trip per hop instead of the reference's four;
@@ -19,6 +20,7 @@
 // replaced (forward 10.8 ms staged vs 8.8 ms direct on the 2M-point foam).
 //
 // Kernels (reference counterparts in src/tracing/pipeline.cu):
+//   padded_*_kernel        (no counterpart: prefix sum of the face counts rounded up to 4)
 //   prepare_foam_kernel    prefetch_adjacent_diff_kernel :546-568  (+ cell/face packing)
 //   adjacent_diff_kernel   prefetch_adjacent_diff_kernel :546-568  (plain half4 table)
 //   repack_sh_kernel       (no counterpart: aligned SH rows)
@@ -42,9 +44,10 @@ namespace rf {
 
 struct FoamView {
     const float4 *cells;        // {x, y, z, density}
-    const uint2 *geo;           // per face: fp16 offset to the neighbour | neighbour's face count
-    const uint2 *link;          // per face: {neighbour index, neighbour's first face}
-    const uint32_t *offsets;    // caller's CSR offsets (entry cell's face range)
+    const uint16_t *geo;        // blocks of 4 faces: half x[4] y[4] z[4], offsets to the neighbours (rf_foam.hpp)
+    const Link *link;           // per face: {neighbour index, its first face, its padded face count}
+    const uint32_t *poff;       // [N+1] first (padded) face entry per cell
+    const uint32_t *offsets;    // caller's CSR offsets (walk statistics only)
     const void *sh;             // SH rows, sh_stride scalars apart
     uint32_t sh_stride;
 };
@@ -68,7 +71,7 @@ struct FwdParams {
     uint32_t *nint;
     float *contribution;
     unsigned long long *stats;
-    uint32_t *trail;        // [trail_cap][trail_slots] winning face entry per hop (optional)
+    uint32_t *trail;        // [trail_cap][trail_slots] cell entered by each hop (optional)
     uint32_t *trail_hops;   // [trail_slots] hops taken by the ray of each thread slot
     uint32_t trail_cap, trail_slots;
     // benchmark
@@ -120,8 +123,12 @@ __device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray) {
         uint32_t tiles_x = (g.img_w + 15u) >> 4;
         uint32_t ty = blk / tiles_x, tx = blk - ty * tiles_x;
         uint32_t wave = tid >> 6, lane = tid & 63u;
-        uint32_t x = (tx << 4) + ((wave & 1u) << 3) + (lane & 7u);
-        uint32_t y = (ty << 4) + ((wave >> 1) << 3) + (lane >> 3);
+        // Z-order inside the wave's 8x8 tile: the 4 / 16 lanes whose addresses the texture path
+        // processes together are a 2x2 / 4x4 pixel block (fewest distinct cells, i.e. cache lines)
+        uint32_t lx = (lane & 1u) | ((lane >> 1) & 2u) | ((lane >> 2) & 4u);
+        uint32_t ly = ((lane >> 1) & 1u) | ((lane >> 2) & 2u) | ((lane >> 3) & 4u);
+        uint32_t x = (tx << 4) + ((wave & 1u) << 3) + lx;
+        uint32_t y = (ty << 4) + ((wave >> 1) << 3) + ly;
         ray = y * g.img_w + x;
         return x < g.img_w && y < g.img_h;
     }
@@ -140,13 +147,12 @@ inline uint32_t grid_blocks(const RayGrid &g) {
 struct ScanResult {
     float t1;
     uint32_t k;     // winning face, relative to the cell's first face; kNone if no exit
-    uint32_t w1;    // second dword of the winning entry (neighbour's face count in the high half)
 };
 
-// t of the ray/bisector hit for one face; dp > 0 <=> the ray leaves through it
-__device__ __forceinline__ void face_hit(uint2 e, float Px, float Py, float Pz, float Ox, float Oy,
-                                         float Oz, float dx, float dy, float dz, float &dp, float &t) {
-    float ox = half_lo(e.x), oy = half_hi(e.x), oz = half_lo(e.y);
+// t of the ray/bisector hit for one face with offset o; dp > 0 <=> the ray leaves through it
+__device__ __forceinline__ void face_hit(float ox, float oy, float oz, float Px, float Py, float Pz,
+                                         float Ox, float Oy, float Oz, float dx, float dy, float dz,
+                                         float &dp, float &t) {
     dp = dot3(ox, oy, oz, dx, dy, dz);
     float vx = fma_(ox, 0.5f, Px) - Ox;
     float vy = fma_(oy, 0.5f, Py) - Oy;
@@ -179,40 +185,45 @@ __device__ __forceinline__ v2f div2(v2f n, v2f d) {
     return fma2(r1, y1, q1);
 }
 
-struct __attribute__((aligned(8))) GeoPair {
-    uint2 a, b;
+struct __attribute__((aligned(8))) GeoXY {
+    uint32_t x01, x23, y01, y23;
+};
+struct __attribute__((aligned(8))) GeoZ {
+    uint32_t z01, z23;
 };
 
-// Nearest exit of the ray from the cell whose faces are geo entries src[0..cnt); ascending order,
-// strict '<' (the first minimum wins, like the reference).  Four faces per iteration are evaluated
-// branch-free, two at a time in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two faces
-// per VALU slot), while the next four are fetched (two 16-byte gathers; a list starts on an 8-byte
-// boundary, which this hardware serves -- scripts/probe/unaligned.hip).  Reads may run up to 7
-// entries past the list: the table is padded with kFacePad zero entries.
-__device__ __forceinline__ ScanResult scan_faces(const uint2 *src, uint32_t cnt, float Px, float Py,
+// Nearest exit of the ray from the cell whose `cnt` (a multiple of 4, padding included) face
+// entries start at `blk` in the geo table; ascending order, strict '<' (the first minimum wins,
+// like the reference).  Four faces per iteration, branch-free, two at a time in packed fp32
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32); a block arrives as one 16-byte and one 8-byte
+// load (blocks are 8-byte aligned, which this hardware serves -- scripts/probe/unaligned.hip).
+// Padding entries have a zero offset: dp = 0, never a candidate.  The winner is tracked relative
+// to the block being scanned (`rel`, inline constants 0..3) and rebased once per iteration,
+// instead of materialising k+j per face.
+__device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t cnt, float Px, float Py,
                                                  float Pz, float Ox, float Oy, float Oz, float dx,
                                                  float dy, float dz) {
     ScanResult r;
     r.t1 = __builtin_inff();
-    r.k = kNone;
-    r.w1 = 0u;
+    constexpr int kUnset = -0x40000000;
+    int rel = kUnset;
     const v2f P2x = {Px, Px}, P2y = {Py, Py}, P2z = {Pz, Pz};
     const v2f O2x = {Ox, Ox}, O2y = {Oy, Oy}, O2z = {Oz, Oz};
     const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
     const v2f half2 = {0.5f, 0.5f};
-    GeoPair e0 = *reinterpret_cast<const GeoPair *>(src);
-    GeoPair e1 = *reinterpret_cast<const GeoPair *>(src + 2);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
     for (uint32_t k = 0; k < cnt; k += 4) {
-        const GeoPair n0 = *reinterpret_cast<const GeoPair *>(src + k + 4);
-        const GeoPair n1 = *reinterpret_cast<const GeoPair *>(src + k + 6);
-        const uint2 e[4] = {e0.a, e0.b, e1.a, e1.b};
+        const GeoXY A = *reinterpret_cast<const GeoXY *>(src);
+        const GeoZ B = *reinterpret_cast<const GeoZ *>(src + 4);
+        src += 6;
+        rel -= 4;
         float dp[4], t[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const uint2 ea = e[2 * h], eb = e[2 * h + 1];
-            const v2f ox = {half_lo(ea.x), half_lo(eb.x)};
-            const v2f oy = {half_hi(ea.x), half_hi(eb.x)};
-            const v2f oz = {half_lo(ea.y), half_lo(eb.y)};
+            const uint32_t wx = h ? A.x23 : A.x01, wy = h ? A.y23 : A.y01, wz = h ? B.z23 : B.z01;
+            const v2f ox = {half_lo(wx), half_hi(wx)};
+            const v2f oy = {half_lo(wy), half_hi(wy)};
+            const v2f oz = {half_lo(wz), half_hi(wz)};
             // dp = fma(ox,dx, fma(oy,dy, oz*dz))
             const v2f dpp = fma2(ox, d2x, fma2(oy, d2y, oz * d2z));
             // v = (P + o/2) - O ; num = fma(vx,ox, fma(vy,oy, vz*oz))
@@ -228,22 +239,21 @@ __device__ __forceinline__ ScanResult scan_faces(const uint2 *src, uint32_t cnt,
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bool better = (dp[j] > 0.0f) && (k + j < cnt) && (t[j] < r.t1);
+            bool better = (dp[j] > 0.0f) && (t[j] < r.t1);
             r.t1 = better ? t[j] : r.t1;
-            r.k = better ? k + j : r.k;
-            r.w1 = better ? e[j].y : r.w1;
+            rel = better ? j : rel;
         }
-        e0 = n0;
-        e1 = n1;
     }
+    // after a lane's last iteration its block base is cnt - 4
+    r.k = (rel > kUnset / 2) ? (cnt - 4u) + (uint32_t)rel : kNone;
     return r;
 }
 
-// fat view of face entry e: {geo.x, geo.y, neighbour index, neighbour's first face}
-__device__ __forceinline__ uint4 load_face(const FoamView &fv, uint32_t e) {
-    const uint2 g = fv.geo[e];
-    const uint2 l = fv.link[e];
-    return make_uint4(g.x, g.y, l.x, l.y);
+// fp16-rounded offset from cell p to its neighbour q, as the face tables hold it (pack_diff)
+__device__ __forceinline__ void face_offset(const float4 &p, const float4 &q, float &ox, float &oy, float &oz) {
+    ox = (float)(_Float16)(q.x - p.x);
+    oy = (float)(_Float16)(q.y - p.y);
+    oz = (float)(_Float16)(q.z - p.z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -409,8 +419,8 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
     uint32_t nb = 0, cnt = 0;
     float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (alive) {
-        nb = fv.offsets[cur];
-        cnt = fv.offsets[cur + 1] - nb;
+        nb = fv.poff[cur];
+        cnt = fv.poff[cur + 1] - nb;
         head = fv.cells[cur];
     }
     uint32_t wave_steps = 0;
@@ -425,27 +435,26 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
         ScanResult sr;
         sr.t1 = __builtin_inff();
         sr.k = kNone;
-        sr.w1 = 0u;
         if (alive) {
-            sr = scan_faces(fv.geo + nb, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
+            sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
             if (want_stats) {
                 st_cells++;
-                st_faces += cnt;
+                st_faces += fv.offsets[cur + 1] - fv.offsets[cur];
             }
             if (sr.k == kNone) alive = false;
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (alive) {
-            const uint2 link = fv.link[nb + sr.k];
-            nxt = link.x;
-            nnb = link.y;
-            ncnt = sr.w1 >> 16;
+            const Link link = fv.link[nb + sr.k];
+            nxt = link.nbr;
+            nnb = link.first;
+            ncnt = link.count;
             nhead = fv.cells[nxt];
             if constexpr (!BENCH) {
-                // trail: the face each hop went through, for trace_backward to replay
+                // trail: the cell each hop enters, for trace_backward to replay
                 if (p.trail) {
-                    if (hops < p.trail_cap) p.trail[(size_t)hops * p.trail_slots + slot] = nb + sr.k;
+                    if (hops < p.trail_cap) p.trail[(size_t)hops * p.trail_slots + slot] = nxt;
                     hops++;
                 }
             }
@@ -899,8 +908,8 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
     uint32_t nb = 0, cnt = 0;
     float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (alive) {
-        nb = fv.offsets[cur];
-        cnt = fv.offsets[cur + 1] - nb;
+        nb = fv.poff[cur];
+        cnt = fv.poff[cur + 1] - nb;
         head = fv.cells[cur];
     }
     // Gradient contributions of the step just finished are scattered at the top of the NEXT
@@ -918,18 +927,17 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
         ScanResult sr;
         sr.t1 = __builtin_inff();
         sr.k = kNone;
-        sr.w1 = 0u;
         if (alive) {
-            sr = scan_faces(fv.geo + nb, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
+            sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
             if (sr.k == kNone) alive = false;
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (alive) {
-            const uint2 link = fv.link[nb + sr.k];
-            nxt = link.x;
-            nnb = link.y;
-            ncnt = sr.w1 >> 16;
+            const Link link = fv.link[nb + sr.k];
+            nxt = link.nbr;
+            nnb = link.first;
+            ncnt = link.count;
             nhead = fv.cells[nxt];
         }
         if (alive) {
@@ -948,9 +956,9 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
 }
 
 // Backward by replaying the trail trace_forward recorded for exactly these rays: hop i of a ray
-// went through fat face entry trail[i]; its t1 is recomputed with the same arithmetic (so it
-// is the same float), and no face list is scanned.  Entries, and the next cell's record, are
-// fetched two / one hops ahead.  A ray with more hops than the trail holds is skipped here and
+// entered cell trail[i]; the t1 of the face crossed is recomputed with the same arithmetic (so it
+// is the same float), and no face list is scanned nor any face table read.  Trail entries and the
+// next cell's record are fetched two / one hops ahead.  A ray with more hops than the trail holds is skipped here and
 // handled by a second launch of the re-walk kernel (backward_kernel), which takes only those.
 template <int DEG, bool HALF, int MODE>
 __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
@@ -977,18 +985,15 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
     const uint32_t max_steps = p.settings.max_intersections;
     const uint32_t recorded = hops < cap ? hops : cap;   // hops present in the trail
 
-    // pipeline registers: e2 = trail[i+2], ent1 = faces[trail[i+1]], ent0 = faces[trail[i]],
-    // q0 = cells[ent0.z]
+    // pipeline registers: id1 = trail[i+1], id0 = trail[i], q0 = cells[id0]
     float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint4 ent0 = make_uint4(0u, 0u, 0u, 0u), ent1 = make_uint4(0u, 0u, 0u, 0u);
     float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t e2 = 0;
+    uint32_t id0 = 0, id1 = 0;
     if (alive) {
         head = fv.cells[cur];
-        if (recorded > 0) ent0 = load_face(fv, p.trail[slot]);
-        if (recorded > 1) ent1 = load_face(fv, p.trail[slots + slot]);
-        if (recorded > 2) e2 = p.trail[2 * slots + slot];
-        if (recorded > 0) q0 = fv.cells[ent0.z];
+        if (recorded > 0) id0 = p.trail[slot];
+        if (recorded > 1) id1 = p.trail[slots + slot];
+        if (recorded > 0) q0 = fv.cells[id0];
     }
 
     StepGrad G;
@@ -1006,41 +1011,37 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
             if (n > max_steps) alive = false;
         }
         if (alive && i >= hops) alive = false;   // forward stopped here (no exit face / step cap / opaque)
-        // (A) prefetch: cell record of hop i+1, face entry of hop i+2, trail entry of hop i+3
+        // (A) prefetch: cell record of hop i+1, trail entry of hop i+2
         float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint4 ent2 = make_uint4(0u, 0u, 0u, 0u);
-        uint32_t e3 = 0;
+        uint32_t id2 = 0;
         if (alive) {
-            if (i + 1 < recorded) q1 = fv.cells[ent1.z];
-            if (i + 2 < recorded) ent2 = load_face(fv, e2);
-            if (i + 3 < recorded) e3 = p.trail[(size_t)(i + 3) * slots + slot];
+            if (i + 1 < recorded) q1 = fv.cells[id1];
+            if (i + 2 < recorded) id2 = p.trail[(size_t)(i + 2) * slots + slot];
         }
-        // (B) this hop
-        uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+        // (B) this hop: the face crossed is the bisector of (cur, id0); its fp16 offset is
+        // recomputed from the two cell records exactly as rf_prepare_foam rounds it
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float t1 = 0.0f;
         if (alive) {
-            ent = ent0;
             nhead = q0;
-            float dp;
-            face_hit(make_uint2(ent.x, ent.y), head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
+            float ox, oy, oz, dp;
+            face_offset(head, nhead, ox, oy, oz);
+            face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
         }
         if (alive) {
             if (t1 > R.t0) {
                 if (!backward_segment<DEG, HALF>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
             }
             R.t0 = __builtin_fmaxf(R.t0, t1);
-            cur = ent.z;
+            cur = id0;
             head = nhead;
             i++;
         }
         // (C) rotate the pipeline; the asm pins make the loads complete HERE, before the atomics
-        ent0 = ent1;
-        ent1 = ent2;
+        id0 = id1;
+        id1 = id2;
         q0 = q1;
-        e2 = e3;
-        asm volatile("" : "+v"(ent1.x), "+v"(ent1.y), "+v"(ent1.z), "+v"(ent1.w));
-        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(e2));
+        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(id1));
         // (D) scatter this hop's gradients
         scatter_pending<DEG, MODE>(p, lane, sh, G);
     }
@@ -1209,15 +1210,13 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
     const uint32_t recorded = hops < cap ? hops : cap;
 
     float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint4 ent0 = make_uint4(0u, 0u, 0u, 0u), ent1 = make_uint4(0u, 0u, 0u, 0u);
     float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t e2 = 0;
+    uint32_t id0 = 0, id1 = 0;
     if (alive) {
         head = fv.cells[cur];
-        if (recorded > 0) ent0 = load_face(fv, p.trail[slot]);
-        if (recorded > 1) ent1 = load_face(fv, p.trail[slots + slot]);
-        if (recorded > 2) e2 = p.trail[2 * slots + slot];
-        if (recorded > 0) q0 = fv.cells[ent0.z];
+        if (recorded > 0) id0 = p.trail[slot];
+        if (recorded > 1) id1 = p.trail[slots + slot];
+        if (recorded > 0) q0 = fv.cells[id0];
     }
 
     StepGrad G;
@@ -1234,35 +1233,31 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
             }
             if (alive && i >= hops) alive = false;
             float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            uint4 ent2 = make_uint4(0u, 0u, 0u, 0u);
-            uint32_t e3 = 0;
+            uint32_t id2 = 0;
             if (alive) {
-                if (i + 1 < recorded) q1 = fv.cells[ent1.z];
-                if (i + 2 < recorded) ent2 = load_face(fv, e2);
-                if (i + 3 < recorded) e3 = p.trail[(size_t)(i + 3) * slots + slot];
+                if (i + 1 < recorded) q1 = fv.cells[id1];
+                if (i + 2 < recorded) id2 = p.trail[(size_t)(i + 2) * slots + slot];
             }
-            uint4 ent = make_uint4(0u, 0u, 0u, 0u);
             float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             float t1 = 0.0f;
             if (alive) {
-                ent = ent0;
                 nhead = q0;
-                float dp;
-                face_hit(make_uint2(ent.x, ent.y), head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
+                float ox, oy, oz, dp;
+                face_offset(head, nhead, ox, oy, oz);
+                face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
             }
             if (alive) {
                 if (t1 > R.t0) {
                     if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
                 }
                 R.t0 = __builtin_fmaxf(R.t0, t1);
-                cur = ent.z;
+                cur = id0;
                 head = nhead;
                 i++;
             }
-            ent0 = ent1;
-            ent1 = ent2;
+            id0 = id1;
+            id1 = id2;
             q0 = q1;
-            e2 = e3;
 
             // add this hop's gradients to the block cache (or straight to memory on a table conflict)
             {
@@ -1380,25 +1375,108 @@ __device__ __forceinline__ uint2 pack_diff(float dx, float dy, float dz) {
     return make_uint2(lo, hi);
 }
 
-// cells[i] = {x,y,z,density}; geo[e] / link[e] = the face tables (rf_foam.hpp).  A wave owns 64
-// consecutive cells and streams their (contiguous) faces with one lane per face, so adjacency reads
-// and table writes are coalesced; the owner of a face is found by binary search in the wave's 65
-// CSR offsets (LDS).  ext_diff != nullptr: take the half offsets from the caller's half4 table
-// instead of recomputing them (trace_benchmark).
+// ---- padded offsets: poff[i] = sum_{j<i} round_up4(offsets[j+1] - offsets[j]) -------------------
+// Three small launches: per-chunk sums (kScanChunk cells per 256-thread block, 4 cells per
+// thread), one block scanning the chunk sums, then the per-cell exclusive scan inside each chunk.
+
+__device__ __forceinline__ uint32_t padded_count(const uint32_t *__restrict__ offsets, uint32_t i, uint32_t n) {
+    return i < n ? ((offsets[i + 1] - offsets[i] + 3u) & ~3u) : 0u;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns the block total
+__device__ __forceinline__ uint32_t block_scan256(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t up = __shfl_up(inc, d, 64);
+        if ((int)lane >= d) inc += up;
+    }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+    total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void padded_chunk_sums_kernel(const uint32_t *__restrict__ offsets,
+                                                                uint32_t n, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t i0 = blockIdx.x * kScanChunk + threadIdx.x * 4u;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) v += padded_count(offsets, i0 + j, n);
+    uint32_t total;
+    (void)block_scan256(v, s_wave, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// in place: sums[b] <- sum of sums[0..b); one block, any number of chunks
+__global__ __launch_bounds__(256) void padded_scan_sums_kernel(uint32_t *__restrict__ sums, uint32_t nchunks) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t per = (nchunks + 255u) / 256u;
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < per; ++j)
+        if (b0 + j < nchunks) v += sums[b0 + j];
+    uint32_t total;
+    uint32_t run = block_scan256(v, s_wave, total);
+    for (uint32_t j = 0; j < per; ++j)
+        if (b0 + j < nchunks) {
+            const uint32_t c = sums[b0 + j];
+            sums[b0 + j] = run;
+            run += c;
+        }
+}
+
+__global__ __launch_bounds__(256) void padded_offsets_kernel(const uint32_t *__restrict__ offsets, uint32_t n,
+                                                             const uint32_t *__restrict__ sums,
+                                                             uint32_t *__restrict__ poff) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t i0 = blockIdx.x * kScanChunk + threadIdx.x * 4u;
+    uint32_t c[4], v = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        c[j] = padded_count(offsets, i0 + j, n);
+        v += c[j];
+    }
+    uint32_t total;
+    uint32_t run = sums[blockIdx.x] + block_scan256(v, s_wave, total);
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        if (i0 + j <= n) poff[i0 + j] = run;   // i0+j == n: the padded total
+        run += c[j];
+    }
+}
+
+// cells[i] = {x,y,z,density}; geo / link = the face tables (rf_foam.hpp).  A wave owns 64
+// consecutive cells and streams their (contiguous, padded) entries with one lane per entry, so
+// adjacency reads and table writes are coalesced; the owner of an entry is found by binary search
+// in the wave's 65 padded offsets (LDS).  ext_diff != nullptr: take the half offsets from the
+// caller's half4 table instead of recomputing them (trace_benchmark).
 template <bool HALF>
 __global__ __launch_bounds__(256) void prepare_foam_kernel(
     const float *__restrict__ points, const void *__restrict__ attributes, uint32_t attr_dim,
     uint32_t num_points, const uint32_t *__restrict__ adj, const uint32_t *__restrict__ offsets,
-    const uint2 *__restrict__ ext_diff, float4 *__restrict__ cells, uint2 *__restrict__ geo,
-    uint2 *__restrict__ link) {
+    const uint32_t *__restrict__ poff, const uint2 *__restrict__ ext_diff, float4 *__restrict__ cells,
+    uint16_t *__restrict__ geo, Link *__restrict__ link) {
     __shared__ uint32_t s_off[4][66];
+    __shared__ uint32_t s_csr[4][66];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t c0 = (blockIdx.x * 4u + wave) * 64u;
     if (c0 >= num_points) return;
     const uint32_t ncells = (num_points - c0 < 64u) ? num_points - c0 : 64u;
     uint32_t *off = s_off[wave];
-    if (lane <= ncells) off[lane] = offsets[c0 + lane];
-    if (lane == 0u) off[ncells] = offsets[c0 + ncells];
+    uint32_t *csr = s_csr[wave];
+    if (lane <= ncells) {
+        off[lane] = poff[c0 + lane];
+        csr[lane] = offsets[c0 + lane];
+    }
+    if (lane == 0u) {
+        off[ncells] = poff[c0 + ncells];
+        csr[ncells] = offsets[c0 + ncells];
+    }
     if (lane < ncells) {
         const uint32_t i = c0 + lane;
         float s = load_attr_scalar<HALF>(attributes, (size_t)i * attr_dim + attr_dim - 1);
@@ -1407,25 +1485,35 @@ __global__ __launch_bounds__(256) void prepare_foam_kernel(
     __builtin_amdgcn_wave_barrier();
     const uint32_t f_begin = off[0], f_end = off[ncells];
     for (uint32_t f = f_begin + lane; f < f_end; f += 64u) {
-        uint32_t lo = 0, hi = ncells;   // owner: last cell whose first face is <= f
+        uint32_t lo = 0, hi = ncells;   // owner: last cell whose first entry is <= f
         while (hi - lo > 1u) {
             const uint32_t mid = (lo + hi) >> 1;
             if (off[mid] <= f) lo = mid; else hi = mid;
         }
-        const uint32_t i = c0 + lo;
-        const uint32_t q = adj[f];
-        uint2 d;
-        if (ext_diff) {
-            d = ext_diff[f];
-            d.y &= 0xFFFFu;
-        } else {
-            const float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
-            const float qx = points[3 * (size_t)q], qy = points[3 * (size_t)q + 1], qz = points[3 * (size_t)q + 2];
-            d = pack_diff(qx - px, qy - py, qz - pz);
+        const uint32_t j = f - off[lo];
+        uint2 d = make_uint2(0u, 0u);
+        Link lk = {0u, 0u, 0u};
+        if (j < csr[lo + 1] - csr[lo]) {
+            const uint32_t i = c0 + lo;
+            const uint32_t src = csr[lo] + j;
+            const uint32_t q = adj[src];
+            if (ext_diff) {
+                d = ext_diff[src];
+            } else {
+                const float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
+                const float qx = points[3 * (size_t)q], qy = points[3 * (size_t)q + 1], qz = points[3 * (size_t)q + 2];
+                d = pack_diff(qx - px, qy - py, qz - pz);
+            }
+            const uint32_t qb = poff[q];
+            lk.nbr = q;
+            lk.first = qb;
+            lk.count = poff[q + 1] - qb;
         }
-        const uint32_t qb = offsets[q], qe = offsets[q + 1];
-        geo[f] = make_uint2(d.x, d.y | ((qe - qb) << 16));
-        link[f] = make_uint2(q, qb);
+        uint16_t *g = geo + (size_t)(f >> 2) * 12u + (f & 3u);
+        g[0] = (uint16_t)(d.x & 0xFFFFu);
+        g[4] = (uint16_t)(d.x >> 16);
+        g[8] = (uint16_t)(d.y & 0xFFFFu);
+        link[f] = lk;
     }
 }
 
@@ -1484,8 +1572,9 @@ static FoamView make_view(const FoamLayout &L, void *ws, const void *attributes,
     FoamView v;
     char *base = static_cast<char *>(ws);
     v.cells = reinterpret_cast<const float4 *>(base + L.cells_off);
-    v.geo = reinterpret_cast<const uint2 *>(base + L.geo_off);
-    v.link = reinterpret_cast<const uint2 *>(base + L.link_off);
+    v.geo = reinterpret_cast<const uint16_t *>(base + L.geo_off);
+    v.link = reinterpret_cast<const Link *>(base + L.link_off);
+    v.poff = reinterpret_cast<const uint32_t *>(base + L.poff_off);
     v.offsets = offsets;
     v.sh = L.sh_repacked ? static_cast<const void *>(base + L.sh_off) : attributes;
     v.sh_stride = L.sh_stride;
@@ -1502,18 +1591,24 @@ static int prepare_impl(int sh_degree, int attr_type, uint32_t num_points, const
     if (num_points == 0) return RF_OK;
     char *base = static_cast<char *>(ws);
     float4 *cells = reinterpret_cast<float4 *>(base + L.cells_off);
-    uint2 *geo = reinterpret_cast<uint2 *>(base + L.geo_off);
-    uint2 *link = reinterpret_cast<uint2 *>(base + L.link_off);
+    uint16_t *geo = reinterpret_cast<uint16_t *>(base + L.geo_off);
+    Link *link = reinterpret_cast<Link *>(base + L.link_off);
+    uint32_t *poff = reinterpret_cast<uint32_t *>(base + L.poff_off);
+    uint32_t *sums = reinterpret_cast<uint32_t *>(base + L.scan_off);
     const uint32_t A = attribute_dim(sh_degree);
-    dim3 grid((num_points + 255u) / 256u), block(256);   // 4 waves x 64 cells per block
+    dim3 block(256);
+    // padded offsets; chunks cover cells 0..num_points inclusive (the last entry is the total)
+    const uint32_t nchunks = num_points / kScanChunk + 1u;
+    hipLaunchKernelGGL(padded_chunk_sums_kernel, dim3(nchunks), block, 0, stream, offsets, num_points, sums);
+    hipLaunchKernelGGL(padded_scan_sums_kernel, dim3(1), block, 0, stream, sums, nchunks);
+    hipLaunchKernelGGL(padded_offsets_kernel, dim3(nchunks), block, 0, stream, offsets, num_points, sums, poff);
+    dim3 grid((num_points + 255u) / 256u);   // 4 waves x 64 cells per block
     if (half)
         hipLaunchKernelGGL(prepare_foam_kernel<true>, grid, block, 0, stream, points, attributes, A, num_points,
-                           adj, offsets, static_cast<const uint2 *>(ext_diff), cells, geo, link);
+                           adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link);
     else
         hipLaunchKernelGGL(prepare_foam_kernel<false>, grid, block, 0, stream, points, attributes, A, num_points,
-                           adj, offsets, static_cast<const uint2 *>(ext_diff), cells, geo, link);
-    // zero the padding so over-reads past the last cell see well-defined (never selected) entries
-    (void)hipMemsetAsync(geo + adj_size, 0, (size_t)kFacePad * 8, stream);
+                           adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link);
     if (L.sh_repacked) {
         size_t total = (size_t)num_points * L.sh_stride;
         dim3 g2((unsigned)((total + 255) / 256));
