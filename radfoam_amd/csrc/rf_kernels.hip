@@ -11,8 +11,9 @@
 //   3. composites the segment (forward) / accumulates gradients (backward).
 // Forward records the face of every hop (the "trail"); backward replays it instead of scanning
 // again, and sums gradient rows in a block-level LDS write-combining cache before they go to
-// global atomics.  Blocks are handed to XCDs in contiguous chunks of the tile order so each
-// XCD's private L2 sees one band of the image (= one slab of the foam).
+// global atomics.  Tiles are dealt to the XCDs in half-row strips, round-robin, so each XCD's
+// private L2 sees whole strips of the image while all XCDs get the same mix of cheap and
+// expensive image regions.
 //
 // Tried and measured out: staging the wave's distinct cells' face lists in
 // LDS (global_load_lds DMA + ballot/readlane dedupe).  The lanes of a tile sit in 16-24
@@ -108,20 +109,52 @@ constexpr int kBlock = 256;
 // ------------------------------------------------------------------------------------------
 // block -> tile, lane -> ray
 
-// The dispatcher places block b on XCD b%8.  Give XCD x the x-th contiguous chunk of the
-// logical block order instead of every 8th block (bijection for any grid size).
-__device__ __forceinline__ uint32_t xcd_chunked_block(uint32_t b, uint32_t nb) {
-    uint32_t x = b & 7u, local = b >> 3;
-    uint32_t q = nb >> 3, r = nb & 7u;
-    return x * q + (x < r ? x : r) + local;
+// The dispatcher places block b on XCD b%8, and every XCD has a private L2.  Tiles are dealt to
+// the XCDs in chunks of `chunk` consecutive tiles of the row-major tile order (half an image row of
+// tiles): XCD x works through chunks x, x+8, x+16, ...  A chunk is a contiguous strip of the image
+// (one slab of the foam for that XCD's L2); dealing them round-robin gives every XCD strips from
+// all over the image, so that the XCDs finish together even though rays through different image
+// regions walk very different numbers of cells (measured: contiguous eighths of the image finish
+// between 5.8 and 7.7 ms).  The launch is padded to whole rounds of 8 chunks; blocks whose tile
+// falls past the end own no rays.
+__device__ __forceinline__ uint32_t dealt_tile(uint32_t b, uint32_t chunk) {
+    const uint32_t x = b & 7u, i = b >> 3;
+    const uint32_t j = i / chunk, o = i - j * chunk;
+    return (j * 8u + x) * chunk + o;
 }
 
-__device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray) {
-    uint32_t blk = xcd_chunked_block(blockIdx.x, gridDim.x);
-    uint32_t tid = threadIdx.x;
+inline __host__ __device__ uint32_t num_tiles(const RayGrid &g) {
+    if (g.img_w) return ((g.img_w + 15u) >> 4) * ((g.img_h + 15u) >> 4);
+    return (g.num_rays + (uint32_t)kBlock - 1u) / (uint32_t)kBlock;
+}
+
+inline __host__ __device__ uint32_t tile_chunk(const RayGrid &g) {
+    if (g.img_w) {
+        const uint32_t tiles_x = (g.img_w + 15u) >> 4;
+        return tiles_x > 1u ? (tiles_x + 1u) >> 1 : 1u;
+    }
+    return 16u;
+}
+
+// blocks to launch: whole rounds of 8 chunks
+inline uint32_t launch_blocks(const RayGrid &g) {
+    const uint32_t nt = num_tiles(g);
+    if (nt == 0) return 0;
+    const uint32_t round = 8u * tile_chunk(g);
+    return (nt + round - 1u) / round * round;
+}
+
+// ray and trail slot of this thread; false when it owns no ray (slot == kNone: not even a slot)
+__device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray, uint32_t &slot) {
+    const uint32_t tile = dealt_tile(blockIdx.x, tile_chunk(g));
+    const uint32_t tid = threadIdx.x;
+    ray = 0;
+    slot = kNone;
+    if (tile >= num_tiles(g)) return false;
+    slot = tile * (uint32_t)kBlock + tid;
     if (g.img_w) {
         uint32_t tiles_x = (g.img_w + 15u) >> 4;
-        uint32_t ty = blk / tiles_x, tx = blk - ty * tiles_x;
+        uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
         uint32_t wave = tid >> 6, lane = tid & 63u;
         // Z-order inside the wave's 8x8 tile: the 4 / 16 lanes whose addresses the texture path
         // processes together are a 2x2 / 4x4 pixel block (fewest distinct cells, i.e. cache lines)
@@ -132,13 +165,8 @@ __device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray) {
         ray = y * g.img_w + x;
         return x < g.img_w && y < g.img_h;
     }
-    ray = blk * (uint32_t)kBlock + tid;
+    ray = slot;
     return ray < g.num_rays;
-}
-
-inline uint32_t grid_blocks(const RayGrid &g) {
-    if (g.img_w) return ((g.img_w + 15u) >> 4) * ((g.img_h + 15u) >> 4);
-    return (g.num_rays + (uint32_t)kBlock - 1u) / (uint32_t)kBlock;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -361,9 +389,12 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS>
 __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
     const uint32_t lane = threadIdx.x & 63u;
+#ifdef RF_EXPERIMENT_TIMELINE
+    const unsigned long long tl_start = wall_clock64();
+#endif
 
-    uint32_t ray;
-    bool alive = map_ray(p.grid, ray);
+    uint32_t ray, slot;
+    bool alive = map_ray(p.grid, ray, slot);
     const FoamView &fv = p.foam;
 
     float Ox = 0.0f, Oy = 0.0f, Oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 1.0f;
@@ -425,7 +456,6 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
     }
     uint32_t wave_steps = 0;
     uint32_t hops = 0;
-    const uint32_t slot = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     while (ballot(alive) != 0ull) {
         wave_steps++;
         if (alive) {
@@ -502,7 +532,7 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
     }
 
     if constexpr (!BENCH) {
-        if (p.trail) p.trail_hops[slot] = valid ? hops : 0u;
+        if (p.trail && slot != kNone) p.trail_hops[slot] = valid ? hops : 0u;
     }
     if (!valid) return;
     if constexpr (BENCH) {
@@ -522,6 +552,17 @@ __global__ __launch_bounds__(kBlock) void forward_kernel(FwdParams p) {
             reinterpret_cast<float4 *>(p.rgba)[ray] = make_float4(Cr, Cg, Cb, a);
         }
         if (p.nint) p.nint[ray] = n;
+#ifdef RF_EXPERIMENT_TIMELINE
+        // per-block record behind the 8 counters: {XCC id | HW_ID << 8, start, end, wave steps}
+        if (want_stats && threadIdx.x == 0) {
+            unsigned long long *rec = p.stats + 8 + 4ull * blockIdx.x;
+            rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg(6164) |
+                     ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 8);
+            rec[1] = tl_start;
+            rec[2] = wall_clock64();
+            rec[3] = wave_steps;
+        }
+#endif
         if (want_stats) {
             atomicAdd(p.stats + 0, st_cells);
             atomicAdd(p.stats + 1, st_faces);
@@ -885,14 +926,14 @@ template <int DEG, bool HALF, int MODE>
 __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
     const uint32_t lane = threadIdx.x & 63u;
 
-    uint32_t ray;
-    bool alive = map_ray(p.grid, ray);
+    uint32_t ray, slot;
+    bool alive = map_ray(p.grid, ray, slot);
     const FoamView &fv = p.foam;
     constexpr int NB = sh_dim(DEG);
     // with a trail: this launch only handles the rays whose hops did not fit in it (the replay
     // kernel did the others)
     if (p.trail_hops) {
-        if (alive && p.trail_hops[blockIdx.x * (uint32_t)kBlock + threadIdx.x] <= p.trail_cap) alive = false;
+        if (alive && p.trail_hops[slot] <= p.trail_cap) alive = false;
         if (__syncthreads_or(alive ? 1 : 0) == 0) return;
     }
 
@@ -963,11 +1004,10 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
 template <int DEG, bool HALF, int MODE>
 __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t ray;
-    bool alive = map_ray(p.grid, ray);
+    uint32_t ray, slot;
+    bool alive = map_ray(p.grid, ray, slot);
     const FoamView &fv = p.foam;
     constexpr int NB = sh_dim(DEG);
-    const uint32_t slot = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     const size_t slots = p.trail_slots;
     const uint32_t cap = p.trail_cap;
 
@@ -1188,10 +1228,9 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
     }
     __syncthreads();
 
-    uint32_t ray;
-    bool alive = map_ray(p.grid, ray);
+    uint32_t ray, slot;
+    bool alive = map_ray(p.grid, ray, slot);
     const FoamView &fv = p.foam;
-    const uint32_t slot = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     const size_t slots = p.trail_slots;
     const uint32_t cap = p.trail_cap;
 
@@ -1641,7 +1680,7 @@ static int dispatch(int sh_degree, bool half, Args &&...args) {
 template <int DEG, bool HALF>
 struct LaunchForward {
     static int run(const FwdParams &p, bool bench, hipStream_t stream) {
-        uint32_t nb = grid_blocks(p.grid);
+        uint32_t nb = launch_blocks(p.grid);
         if (nb == 0) return RF_OK;
         if (bench)
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
@@ -1658,7 +1697,7 @@ struct LaunchForward {
 template <int DEG, bool HALF>
 struct LaunchBackward {
     static int run(const BwdParams &p, int mode, hipStream_t stream) {
-        uint32_t nb = grid_blocks(p.grid);
+        uint32_t nb = launch_blocks(p.grid);
         if (nb == 0) return RF_OK;
         if (p.trail) {
             if (mode == 1)
@@ -1711,7 +1750,7 @@ uint32_t rf_trail_slots(uint32_t num_rays, uint32_t image_width, uint32_t image_
     rf_launch_opts o{};
     o.image_width = image_width;
     o.image_height = image_height;
-    return grid_blocks(make_grid(num_rays, &o)) * (uint32_t)kBlock;
+    return num_tiles(make_grid(num_rays, &o)) * (uint32_t)kBlock;
 }
 
 size_t rf_workspace_bytes(uint32_t num_points, uint32_t point_adjacency_size, int sh_degree,
@@ -1792,7 +1831,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     p.contribution = static_cast<float *>(point_contribution);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
-        if (opts->trail_slots < grid_blocks(p.grid) * (uint32_t)kBlock)
+        if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: trail_slots smaller than rf_trail_slots()");
         p.trail = opts->trail;
         p.trail_hops = opts->trail_hops;
@@ -1853,7 +1892,7 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     p.point_error = static_cast<float *>(point_error);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
-        if (opts->trail_slots < grid_blocks(p.grid) * (uint32_t)kBlock)
+        if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: trail_slots smaller than rf_trail_slots()");
         p.trail = opts->trail;
         p.trail_hops = opts->trail_hops;

@@ -506,7 +506,7 @@ class Pipeline:
 
     # -- extras (no reference counterpart) -------------------------------------------------------
     def walk_statistics(self, points, attributes, point_adjacency, point_adjacency_offsets, rays,
-                        start_point, weight_threshold=None, max_intersections=None):
+                        start_point, weight_threshold=None, max_intersections=None, extra_slots=0):
         """Exact walk counters of one forward pass (cells/faces scanned, hops, segments, lit
         segments) -- the inputs of the algorithmic-bytes figure in bench.py."""
         points_c, attributes_c = points.contiguous(), attributes.contiguous()
@@ -516,7 +516,7 @@ class Pipeline:
         num_rays = self._validate_rays(rays_c, start_c)
         dev = rays_c.device
         settings = self._settings(weight_threshold, max_intersections)
-        stats = torch.zeros(8, dtype=torch.int64, device=dev)
+        stats = torch.zeros(8 + int(extra_slots), dtype=torch.int64, device=dev)
         rgba = torch.empty(tuple(rays_c.shape[:-1]) + (4,), dtype=self._attr_dtype, device=dev)
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
         opts.stats = stats.data_ptr()
@@ -527,7 +527,9 @@ class Pipeline:
                 _ptr(rays_c), _ptr(start_c), 0, None, _ptr(rgba), None, None, None, None,
                 C.byref(opts), _stream_ptr(dev))
         _lib.check(rc)
-        s = stats.cpu().tolist()
+        s = stats[:8].cpu().tolist()
+        if extra_slots:
+            self.last_raw_statistics = stats.cpu()   # experiment builds (scripts/) append records
         return {"cells_scanned": s[0], "faces_scanned": s[1], "hops": s[2], "segments": s[3],
                 "segments_lit": s[4], "num_rays": num_rays, "lane_steps_staged_in_lds": s[5],
                 "wave_steps": s[6]}
