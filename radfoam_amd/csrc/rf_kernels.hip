@@ -1209,7 +1209,7 @@ __device__ __forceinline__ void absorb_all(uint32_t lane, uint32_t key, bool &ac
 
 template <int DEG, bool HALF, bool QUANT>
 #ifndef RF_BWD_WAVES
-#define RF_BWD_WAVES 3
+#define RF_BWD_WAVES 4
 #endif
 __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backward_replay_cached_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
@@ -1220,6 +1220,9 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
     __shared__ uint32_t s_keys[kCacheRows];
     __shared__ uint32_t s_touch[kCacheRows];
     __shared__ uint32_t s_lock[kCacheRows];
+#ifdef RF_EXPERIMENT_TIMELINE
+    const unsigned long long tl_start = wall_clock64();
+#endif
     for (uint32_t i = threadIdx.x; i < (uint32_t)(kCacheRows * STRIDE); i += kBlock) s_rows[i] = 0.0f;
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCacheRows; i += kBlock) {
         s_keys[i] = kNone;
@@ -1403,6 +1406,16 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
             __syncthreads();
         }
     }
+#ifdef RF_EXPERIMENT_TIMELINE
+    if (p.stats && threadIdx.x == 0) {
+        unsigned long long *rec = p.stats + 8 + 4ull * blockIdx.x;
+        rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg(6164) |
+                 ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 8);
+        rec[1] = tl_start;
+        rec[2] = wall_clock64();
+        rec[3] = it;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
