@@ -117,9 +117,14 @@ constexpr int kBlock = 256;
 // regions walk very different numbers of cells (measured: contiguous eighths of the image finish
 // between 5.8 and 7.7 ms).  The launch is padded to whole rounds of 8 chunks; blocks whose tile
 // falls past the end own no rays.
-__device__ __forceinline__ uint32_t dealt_tile(uint32_t b, uint32_t chunk) {
+__device__ __forceinline__ uint32_t dealt_tile(uint32_t b, uint32_t chunk, uint32_t rounds) {
     const uint32_t x = b & 7u, i = b >> 3;
-    const uint32_t j = i / chunk, o = i - j * chunk;
+    uint32_t j = i / chunk;
+    const uint32_t o = i - j * chunk;
+    // rounds are visited from both ends of the image towards its middle (0, last, 1, last-1, ...):
+    // the blocks still running when the launch drains are then neighbours in the image, of
+    // similar length, instead of the longest walks of the frame
+    j = (j & 1u) ? rounds - 1u - (j >> 1) : (j >> 1);
     return (j * 8u + x) * chunk + o;
 }
 
@@ -146,7 +151,8 @@ inline uint32_t launch_blocks(const RayGrid &g) {
 
 // ray and trail slot of this thread; false when it owns no ray (slot == kNone: not even a slot)
 __device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray, uint32_t &slot) {
-    const uint32_t tile = dealt_tile(blockIdx.x, tile_chunk(g));
+    const uint32_t chunk = tile_chunk(g);
+    const uint32_t tile = dealt_tile(blockIdx.x, chunk, gridDim.x / (8u * chunk));
     const uint32_t tid = threadIdx.x;
     ray = 0;
     slot = kNone;
