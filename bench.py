@@ -213,6 +213,7 @@ def main():
     dom_is_bwd = (not args.forward_only) and bwd_ms >= fwd_ms
     dom_bytes, dom_ms = (bytes_bwd, bwd_ms) if dom_is_bwd else (bytes_fwd, fwd_ms)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    dom_traffic = traffic.get("backward_replay_cached_kernel" if dom_is_bwd else "forward_kernel")
     result = {
         "metric": "Mrays/s fwd+bwd @1080p, 2M-pt foam; achieved HBM GB/s vs peak",
         "value": round(value, 3),
@@ -243,9 +244,13 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic.get("backward_replay_cached_kernel" if dom_is_bwd else "forward_kernel"),
+            "traffic": dom_traffic,
             "algorithmic_bytes_per_launch": int(dom_bytes),
             "avg_launch_ms": round(dom_ms, 4),
+            "note": "achieved = SURVEY 8(d) algorithmic bytes (no cache reuse credited) / launch time, so frac can "
+                    "exceed 1 when the walk is served from L2/LDS; traffic = measured HBM bytes per launch "
+                    "(rocprofv3 PMC, profiles/hbm_traffic.json), hbm_measured_GBps = traffic / launch time",
+            "hbm_measured_GBps": (round(dom_traffic / (dom_ms * 1e-3) / 1e9, 1) if dom_traffic else None),
         },
         "detail": {
             "forward_ms": round(fwd_ms, 4), "backward_ms": round(bwd_ms, 4),
