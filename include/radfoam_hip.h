@@ -67,10 +67,10 @@ typedef struct rf_launch_opts {
     uint64_t *stats;          /* optional device uint64[8]: walk counters for the roofline figure     */
                               /*   [0] cells scanned [1] faces scanned [2] hops [3] segments          */
                               /*   [4] lit segments; accumulated with atomics, caller zeroes          */
-    /* Hop trail (optional): rf_trace_forward records, for every ray, the face entry each hop went   */
-    /* through; rf_trace_backward given the SAME buffers (and the same foam, rays, start cells,       */
-    /* quantiles and settings) replays it instead of re-scanning every cell's faces.  Rays with more  */
-    /* than trail_cap hops are re-scanned past that point, so any trail_cap >= 1 is correct.          */
+    /* Hop trail (optional): rf_trace_forward records, for every ray, the cell each hop entered;     */
+    /* rf_trace_backward given the SAME buffers (and the same foam, rays, start cells, quantiles and  */
+    /* settings) replays it instead of re-scanning every cell's faces.  Rays with more than trail_cap */
+    /* hops are walked again by scanning, so any trail_cap >= 1 is correct.                           */
     uint32_t *trail;          /* device uint32[trail_cap][trail_slots]                                */
     uint32_t *trail_hops;     /* device uint32[trail_slots]                                           */
     uint32_t trail_cap;
@@ -107,7 +107,9 @@ int rf_build_adjacent_diff(const float *points, uint32_t num_points,
  * `adjacent_diff` when that is not NULL) and aligned SH rows.
  * The reference does the equivalent (prefetch_adjacent_diff) inside every trace_forward /
  * trace_backward call (pipeline.cu:613-620,667-674); here the result may be reused while
- * points/attributes/adjacency are unchanged (opts->foam_prepared). */
+ * points/attributes/adjacency are unchanged (opts->foam_prepared).  rf_trace_backward's trail
+ * replay derives the fp16 offsets from the points, so a workspace packed from a caller-supplied
+ * `adjacent_diff` must only be reused by rf_trace_benchmark. */
 int rf_prepare_foam(int sh_degree, int attr_type, uint32_t num_points, const float *points,
                     const void *attributes, uint32_t point_adjacency_size,
                     const uint32_t *point_adjacency, const uint32_t *point_adjacency_offsets,
