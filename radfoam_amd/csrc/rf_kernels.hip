@@ -1130,10 +1130,12 @@ __device__ __forceinline__ int cache_find(uint32_t *keys, uint32_t key) {
     return -1;
 }
 
-// LDS row layout of the block cache (floats): [0, 3B) colour gradients, zero padding up to SHP
-// (a multiple of 4), then the density gradient at SHP and the 3 point-gradient components at
-// SHP+1..SHP+3.  The colour part is updated by read-modify-write under a per-row lock (whole
-// float4s), the last float4 only ever by LDS atomics, so the two never touch the same 16 bytes.
+// LDS row layout of the block cache: floats [0, 3B) colour gradients, zero padding up to SHP (a
+// multiple of 4); then four DOUBLES: the density gradient and the 3 point-gradient components.
+// The colour part is updated by read-modify-write under a per-row lock (whole float4s); the
+// doubles only ever by ds_add_f64 -- 9 clocks per conflict-free wave instruction on gfx950 where
+// ds_add_f32 takes 195 (scripts/probe/lds_atomics.hip) -- so the two never touch the same bytes.
+// Sums are rounded to fp32 once, at the flush.
 template <int NB>
 struct CacheLayout {
     static constexpr int NCOEF = 3 * NB;
@@ -1141,13 +1143,13 @@ struct CacheLayout {
     static constexpr int COL_DS = SHP;
     static constexpr int COL_PG = SHP + 1;
     static constexpr int NCOL = SHP + 4;
-    static constexpr int STRIDE = NCOL + 4;   // 16-B aligned rows whose starts rotate through the banks
+    static constexpr int STRIDE = SHP + 8;    // floats: SHP colour slots + 4 doubles; 16-B aligned rows
 };
 
 // Flush rows to global memory (whole block, between barriers).  all == false: only rows whose
 // touch flag is clear; the flags of the others are cleared for the next epoch.
 template <int NB>
-__device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint32_t *touch, bool all,
+__device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint8_t *touch, bool all,
                                             float *attr_grad, float *points_grad,
                                             unsigned long long *g_dbg = nullptr) {
     using L = CacheLayout<NB>;
@@ -1163,12 +1165,14 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint32_
 #endif
             for (uint32_t col = col0; col < (uint32_t)L::NCOL; col += 32u) {
                 float *cell = rows + r * L::STRIDE + col;
-                const float v = *cell;
+                const bool wide = col >= (uint32_t)L::SHP;
+                double *dcell = reinterpret_cast<double *>(rows + r * L::STRIDE + L::SHP) + (wide ? col - (uint32_t)L::SHP : 0u);
+                const float v = wide ? (float)*dcell : *cell;
                 if (v != 0.0f) {
 #ifdef RF_EXPERIMENT_STATS
                     if (g_dbg) atomicAdd(g_dbg + 1, 1ull);
 #endif
-                    *cell = 0.0f;
+                    if (wide) *dcell = 0.0; else *cell = 0.0f;
                     float *dst;
                     if (col < (uint32_t)L::NCOEF) dst = attr_grad + (size_t)key * A + col;
                     else if (col == (uint32_t)L::COL_DS) dst = attr_grad + (size_t)key * A + (A - 1);
@@ -1179,7 +1183,7 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint32_
             }
             if (col0 == 0u) keys[r] = kNone;
         } else if (col0 == 0u) {
-            touch[r] = 0u;
+            touch[r] = (uint8_t)0;
         }
     }
 }
@@ -1205,9 +1209,9 @@ __device__ __forceinline__ void absorb_stage(uint32_t lane, uint32_t key, bool &
 #endif
 template <int NV>
 __device__ __forceinline__ void absorb_all(uint32_t lane, uint32_t key, bool &act, float (&v)[NV]) {
-    absorb_stage<1, NV>(lane, key, act, v);
-    absorb_stage<2, NV>(lane, key, act, v);
-    absorb_stage<4, NV>(lane, key, act, v);
+    if constexpr (RF_ABSORB_STAGES > 0) absorb_stage<1, NV>(lane, key, act, v);
+    if constexpr (RF_ABSORB_STAGES > 1) absorb_stage<2, NV>(lane, key, act, v);
+    if constexpr (RF_ABSORB_STAGES > 2) absorb_stage<4, NV>(lane, key, act, v);
     if constexpr (RF_ABSORB_STAGES > 3) absorb_stage<8, NV>(lane, key, act, v);
     if constexpr (RF_ABSORB_STAGES > 4) absorb_stage<16, NV>(lane, key, act, v);
     if constexpr (RF_ABSORB_STAGES > 5) absorb_stage<32, NV>(lane, key, act, v);
@@ -1224,15 +1228,15 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
     constexpr int STRIDE = L::STRIDE;
     __shared__ __attribute__((aligned(16))) float s_rows[kCacheRows * STRIDE];
     __shared__ uint32_t s_keys[kCacheRows];
-    __shared__ uint32_t s_touch[kCacheRows];
     __shared__ uint32_t s_lock[kCacheRows];
+    __shared__ uint8_t s_touch[kCacheRows];
 #ifdef RF_EXPERIMENT_TIMELINE
     const unsigned long long tl_start = wall_clock64();
 #endif
     for (uint32_t i = threadIdx.x; i < (uint32_t)(kCacheRows * STRIDE); i += kBlock) s_rows[i] = 0.0f;
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCacheRows; i += kBlock) {
         s_keys[i] = kNone;
-        s_touch[i] = 0u;
+        s_touch[i] = (uint8_t)0;
         s_lock[i] = 0u;
     }
     __syncthreads();
@@ -1334,8 +1338,8 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
                             if (v[k] != 0.0f) grad_add(dst + k, v[k]);
                     }
                     if (act && s_row >= 0) {
-                        s_touch[s_row] = 1u;
-                        atomicAdd(s_rows + s_row * STRIDE + L::COL_DS, v[A - 1]);
+                        s_touch[s_row] = (uint8_t)1;
+                        atomicAdd(reinterpret_cast<double *>(s_rows + s_row * STRIDE + L::SHP), (double)v[A - 1]);
                     }
 #ifdef RF_X_NO_LITADD
                     if (act && s_row >= 0 && v[0] == 123.456f) s_rows[s_row * STRIDE] = v[1] + v[5];
@@ -1364,15 +1368,14 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
                     }
 #endif
                 } else if (ballot(G.has) != 0ull) {
-                    absorb_all<1>(lane, G.cur, act, dsv);
                     if (act) {
                         const int s_row = cache_find(s_keys, G.cur);
                         if (s_row >= 0) {
-                            s_touch[s_row] = 1u;
+                            s_touch[s_row] = (uint8_t)1;
 #ifdef RF_X_NO_DENSADD
                             if (dsv[0] == 123.456f) s_rows[s_row * STRIDE] = dsv[0];
 #else
-                            atomicAdd(s_rows + s_row * STRIDE + L::COL_DS, dsv[0]);
+                            atomicAdd(reinterpret_cast<double *>(s_rows + s_row * STRIDE + L::SHP), (double)dsv[0]);
 #endif
                         } else {
                             grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), dsv[0]);
@@ -1383,15 +1386,14 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
                 if (ballot(G.has && G.pg_on) != 0ull) {
                     bool pact = G.has && G.pg_on;
                     float pv[3] = {G.px, G.py, G.pz};
-                    absorb_all<3>(lane, G.prev, pact, pv);
                     if (pact) {
                         const int s_pg = cache_find(s_keys, G.prev);
                         if (s_pg >= 0) {
-                            s_touch[s_pg] = 1u;
-                            float *dst = s_rows + s_pg * STRIDE + L::COL_PG;
-                            atomicAdd(dst + 0, pv[0]);
-                            atomicAdd(dst + 1, pv[1]);
-                            atomicAdd(dst + 2, pv[2]);
+                            s_touch[s_pg] = (uint8_t)1;
+                            double *dst = reinterpret_cast<double *>(s_rows + s_pg * STRIDE + L::SHP) + 1;
+                            atomicAdd(dst + 0, (double)pv[0]);
+                            atomicAdd(dst + 1, (double)pv[1]);
+                            atomicAdd(dst + 2, (double)pv[2]);
                         } else {
                             float *dst = p.points_grad + 3 * (size_t)G.prev;
                             grad_add(dst + 0, pv[0]);
