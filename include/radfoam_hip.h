@@ -163,6 +163,36 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
                        const rf_camera *camera, const uint32_t *start_point_index,
                        uint32_t *ray_rgba, const rf_launch_opts *opts, void *stream);
 
+/* ---- the callers on either side of the tracer -------------------------------- */
+
+/* RadFoamScene.get_trace_data, radfoam_model/scene.py:202-217, in one pass:
+ *   attributes[i] = [ att_dc[i][0..3) | att_sh[i][0..A-4) | activation_scale * softplus(density[i], beta=10) ]
+ * cast to the pipeline's attribute type (fp32, or fp16 RNE).  att_dc [N][3], att_sh [N][A-4]
+ * (may be NULL when A == 4), density [N] are fp32 device arrays; attributes is [N][A]. */
+int rf_pack_attributes(int sh_degree, int attr_type, uint32_t num_points, const float *att_dc,
+                       const float *att_sh, const float *density, float activation_scale,
+                       void *attributes, void *stream);
+
+/* Its backward: attr_grad is the fp32 [N][A] gradient trace_backward produced; writes
+ * att_dc_grad [N][3], att_sh_grad [N][A-4] and density_grad[i] = attr_grad[i][A-1] *
+ * activation_scale * d softplus(density[i]) (evaluated as torch's softplus_backward does). */
+int rf_pack_attributes_backward(int sh_degree, uint32_t num_points, const float *density,
+                                float activation_scale, const float *attr_grad, float *att_dc_grad,
+                                float *att_sh_grad, float *density_grad, void *stream);
+
+/* radfoam.nn for a few queries (the entry cell of each camera: scene.py:224-234, benchmark.py:89;
+ * reference: triangulation_bindings.cpp:142-181 over the AABB tree of aabb_tree.cu:343-415).
+ * Exact nearest point by squared fp32 distance, the lowest index among exact ties; cost
+ * O(num_points * num_queries).  scratch: num_queries * 8 bytes of device memory. */
+int rf_nearest_point(const float *points, uint32_t num_points, const float *queries,
+                     uint32_t num_queries, uint32_t *indices, void *scratch, void *stream);
+
+/* radfoam.farthest_neighbor, src/delaunay/triangulation_ops.cu:9-44: per point the first farthest
+ * Delaunay neighbour (0xFFFFFFFF if none) and the mean half-distance to its neighbours. */
+int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_t *point_adjacency,
+                         const uint32_t *point_adjacency_offsets, uint32_t *indices,
+                         float *cell_radius, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,10 +8,11 @@ include/radfoam_hip.h; everything else the reference module exports is a torch/s
 package ``radfoam/`` at the repo root.
 """
 from .pipeline import Pipeline, create_pipeline
+from .scene_ops import pack_attributes
 from .shims import (BatchFetcher, Triangulation, TriangulationFailedError, Viewer, build_aabb_tree,
                     farthest_neighbor, nn, run_with_viewer)
 
 __all__ = [
     "Pipeline", "create_pipeline", "Triangulation", "TriangulationFailedError", "build_aabb_tree",
-    "nn", "farthest_neighbor", "BatchFetcher", "Viewer", "run_with_viewer",
+    "nn", "farthest_neighbor", "BatchFetcher", "Viewer", "run_with_viewer", "pack_attributes",
 ]

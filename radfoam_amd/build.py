@@ -5,9 +5,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = [os.path.join(_HERE, "csrc", "rf_kernels.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", "rf_kernels.hip"), os.path.join(_HERE, "csrc", "rf_scene_ops.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "rf_math.hpp"), os.path.join(_HERE, "csrc", "rf_foam.hpp"),
-           os.path.join(_HERE, "csrc", "rf_wave.hpp"),
+           os.path.join(_HERE, "csrc", "rf_wave.hpp"), os.path.join(_HERE, "csrc", "rf_host.hpp"),
            os.path.join(os.path.dirname(_HERE), "include", "radfoam_hip.h")]
 OUTPUT = os.path.join(_HERE, "libradfoam_hip.so")
 

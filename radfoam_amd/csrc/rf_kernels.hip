@@ -35,6 +35,7 @@
 
 #include "../../include/radfoam_hip.h"
 #include "rf_foam.hpp"
+#include "rf_host.hpp"
 #include "rf_math.hpp"
 #include "rf_wave.hpp"
 
@@ -1607,22 +1608,6 @@ __global__ __launch_bounds__(256) void repack_sh_kernel(const T *__restrict__ at
 
 // ------------------------------------------------------------------------------------------
 // host side
-
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char *fmt, const char *detail = "") {
-    std::snprintf(g_err, sizeof(g_err), fmt, detail);
-    return code;
-}
-
-static int check_launch(const char *what) {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
-        return RF_ERR_LAUNCH;
-    }
-    return RF_OK;
-}
 
 static bool valid_instance(int sh_degree, int attr_type) {
     return sh_degree >= 0 && sh_degree <= 3 && (attr_type == RF_ATTR_FLOAT32 || attr_type == RF_ATTR_FLOAT16);

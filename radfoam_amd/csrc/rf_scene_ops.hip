@@ -1,0 +1,253 @@
+// rf_scene_ops.hip -- the reference's per-iteration work on either side of the tracer
+// (SURVEY.md 8(f)), as gfx950 kernels behind the same C-ABI.
+//
+//   pack_attributes_kernel / _backward   RadFoamScene.get_trace_data, radfoam_model/scene.py:202-217:
+//                                        attributes = cat[att_dc, att_sh, scale * softplus(density, beta=10)]
+//                                        .to(attr_dtype) -- three torch ops (two concatenations and a cast, each
+//                                        re-materialising N*A scalars) fused into one pass, plus its backward
+//   nearest_point_kernel                 radfoam.nn for camera positions (torch_bindings/triangulation_bindings.cpp
+//                                        :142-181, src/aabb_tree/aabb_tree.cu:343-415): exact, brute force --
+//                                        24 MB of points per pass is microseconds of HBM time for the handful
+//                                        of cameras scene.py:224-234 / benchmark.py:89 ask about
+//   farthest_neighbor_kernel             src/delaunay/triangulation_ops.cu:9-44 (densification statistics)
+//
+// All HBM-bound streaming / gather kernels; no LDS tiling is needed beyond the block reductions.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "../../include/radfoam_hip.h"
+#include "rf_foam.hpp"
+#include "rf_host.hpp"
+#include "rf_math.hpp"
+
+namespace rf {
+
+// log(1 + e) for e >= 0 without the cancellation of forming 1 + e first (Kahan: log(u) * e / (u - 1))
+__device__ __forceinline__ float log1p_(float e) {
+    const float u = 1.0f + e;
+    if (u == 1.0f) return e;
+    return log_(u) * (e / (u - 1.0f));
+}
+
+constexpr float kSoftplusBeta = 10.0f;        // scene.py:203  F.softplus(self.density, beta=10)
+constexpr float kSoftplusThreshold = 20.0f;   // torch default: linear above beta * x = 20
+
+__device__ __forceinline__ float softplus_(float x) {
+    const float z = x * kSoftplusBeta;
+    return z > kSoftplusThreshold ? x : log1p_(exp_(z)) / kSoftplusBeta;
+}
+
+// d softplus / dx, the way torch's softplus_backward evaluates it: z / (z + 1) with z = exp(beta x)
+__device__ __forceinline__ float softplus_grad_(float x) {
+    const float z = x * kSoftplusBeta;
+    if (z > kSoftplusThreshold) return 1.0f;
+    const float ez = exp_(z);
+    return ez / (ez + 1.0f);
+}
+
+template <typename T>
+__device__ __forceinline__ T to_attr(float v);
+template <>
+__device__ __forceinline__ float to_attr<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ uint16_t to_attr<uint16_t>(float v) { return float_to_half_bits(v); }
+
+// one thread per output scalar: writes are fully coalesced, the three sources are read in runs
+template <typename T>
+__global__ __launch_bounds__(256) void pack_attributes_kernel(const float *__restrict__ att_dc,
+                                                              const float *__restrict__ att_sh,
+                                                              const float *__restrict__ density, float scale,
+                                                              uint32_t num_points, uint32_t attr_dim,
+                                                              T *__restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)num_points * attr_dim;
+    if (idx >= total) return;
+    const uint32_t row = (uint32_t)(idx / attr_dim), col = (uint32_t)(idx - (size_t)row * attr_dim);
+    const uint32_t nsh = attr_dim - 4u;   // SH coefficients beyond the DC term
+    float v;
+    if (col < 3u) v = att_dc[(size_t)row * 3u + col];
+    else if (col < attr_dim - 1u) v = att_sh[(size_t)row * nsh + (col - 3u)];
+    else v = scale * softplus_(density[row]);
+    out[idx] = to_attr<T>(v);
+}
+
+__global__ __launch_bounds__(256) void pack_attributes_backward_kernel(
+    const float *__restrict__ density, float scale, uint32_t num_points, uint32_t attr_dim,
+    const float *__restrict__ attr_grad, float *__restrict__ att_dc_grad, float *__restrict__ att_sh_grad,
+    float *__restrict__ density_grad) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)num_points * attr_dim;
+    if (idx >= total) return;
+    const uint32_t row = (uint32_t)(idx / attr_dim), col = (uint32_t)(idx - (size_t)row * attr_dim);
+    const uint32_t nsh = attr_dim - 4u;
+    const float g = attr_grad[idx];
+    if (col < 3u) att_dc_grad[(size_t)row * 3u + col] = g;
+    else if (col < attr_dim - 1u) att_sh_grad[(size_t)row * nsh + (col - 3u)] = g;
+    else density_grad[row] = (g * scale) * softplus_grad_(density[row]);
+}
+
+// ---- nearest point --------------------------------------------------------------------------------
+// key = squared distance bits << 32 | index: for non-negative floats the bit pattern orders like
+// the value, so a 64-bit integer minimum is the nearest point, the lowest index among exact ties.
+constexpr uint32_t kNnPerThread = 8;
+
+__device__ __forceinline__ unsigned long long min_u64(unsigned long long a, unsigned long long b) {
+    return a < b ? a : b;
+}
+
+__global__ __launch_bounds__(256) void nearest_point_kernel(const float *__restrict__ points, uint32_t num_points,
+                                                            const float *__restrict__ queries,
+                                                            uint32_t num_queries,
+                                                            unsigned long long *__restrict__ best) {
+    __shared__ unsigned long long s_wave[4];
+    const uint32_t base = (blockIdx.x * 256u + threadIdx.x) * kNnPerThread;
+    float px[kNnPerThread], py[kNnPerThread], pz[kNnPerThread];
+#pragma unroll
+    for (uint32_t j = 0; j < kNnPerThread; ++j) {
+        const uint32_t i = base + j;
+        const bool ok = i < num_points;
+        px[j] = ok ? points[3 * (size_t)i] : 0.0f;
+        py[j] = ok ? points[3 * (size_t)i + 1] : 0.0f;
+        pz[j] = ok ? points[3 * (size_t)i + 2] : 0.0f;
+    }
+    for (uint32_t q = 0; q < num_queries; ++q) {
+        const float qx = queries[3 * (size_t)q], qy = queries[3 * (size_t)q + 1], qz = queries[3 * (size_t)q + 2];
+        unsigned long long key = ~0ull;
+#pragma unroll
+        for (uint32_t j = 0; j < kNnPerThread; ++j) {
+            const float dx = px[j] - qx, dy = py[j] - qy, dz = pz[j] - qz;
+            const float d2 = dot3(dx, dy, dz, dx, dy, dz);
+            const unsigned long long k = ((unsigned long long)f2bits(d2) << 32) | (unsigned long long)(base + j);
+            // NaN distances (non-finite input) never win; out-of-range slots neither
+            key = (base + j < num_points && d2 == d2) ? min_u64(key, k) : key;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = min_u64(key, o);
+        }
+        if ((threadIdx.x & 63u) == 0u) s_wave[threadIdx.x >> 6] = key;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long m = min_u64(min_u64(s_wave[0], s_wave[1]), min_u64(s_wave[2], s_wave[3]));
+            if (m != ~0ull) atomicMin(best + q, m);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void nearest_point_finish_kernel(const unsigned long long *__restrict__ best,
+                                                                   uint32_t num_queries,
+                                                                   uint32_t *__restrict__ indices) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < num_queries) indices[q] = (uint32_t)(best[q] & 0xFFFFFFFFull);
+}
+
+// ---- farthest neighbour -----------------------------------------------------------------------------
+// reference: farthest_neighbor_kernel, triangulation_ops.cu:9-44 -- the first strict maximum of the
+// neighbour distances (UINT32_MAX when there is none), and the mean half-distance; the reference's
+// `sum += 0.5 * distance` promotes to double for the addition, restated as such.
+__global__ __launch_bounds__(256) void farthest_neighbor_kernel(const float *__restrict__ points,
+                                                                const uint32_t *__restrict__ adj,
+                                                                const uint32_t *__restrict__ offsets,
+                                                                uint32_t num_points,
+                                                                uint32_t *__restrict__ indices,
+                                                                float *__restrict__ cell_radius) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_points) return;
+    const float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
+    const uint32_t b = offsets[i], e = offsets[i + 1];
+    uint32_t far = kNone;
+    float sum = 0.0f, best = 0.0f;
+    for (uint32_t f = b; f < e; ++f) {
+        const uint32_t q = adj[f];
+        const float dx = points[3 * (size_t)q] - px, dy = points[3 * (size_t)q + 1] - py,
+                    dz = points[3 * (size_t)q + 2] - pz;
+        const float d = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        sum = (float)((double)sum + 0.5 * (double)d);
+        if (d > best) {
+            best = d;
+            far = q;
+        }
+    }
+    indices[i] = far;
+    cell_radius[i] = sum / (float)(e - b);
+}
+
+}  // namespace rf
+
+using namespace rf;
+
+extern "C" {
+
+int rf_pack_attributes(int sh_degree, int attr_type, uint32_t num_points, const float *att_dc,
+                       const float *att_sh, const float *density, float activation_scale, void *attributes,
+                       void *stream) {
+    g_err[0] = 0;
+    const uint32_t A = attribute_dim(sh_degree);
+    if (A == 0 || (attr_type != RF_ATTR_FLOAT32 && attr_type != RF_ATTR_FLOAT16))
+        return fail(RF_ERR_INVALID_ARGUMENT, "Unsupported SH degree or attribute type");
+    if (num_points == 0) return RF_OK;
+    if (!att_dc || !density || !attributes || (A > 4 && !att_sh))
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_pack_attributes: null pointer");
+    const size_t total = (size_t)num_points * A;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (attr_type == RF_ATTR_FLOAT16)
+        hipLaunchKernelGGL(pack_attributes_kernel<uint16_t>, grid, block, 0, s, att_dc, att_sh, density,
+                           activation_scale, num_points, A, static_cast<uint16_t *>(attributes));
+    else
+        hipLaunchKernelGGL(pack_attributes_kernel<float>, grid, block, 0, s, att_dc, att_sh, density,
+                           activation_scale, num_points, A, static_cast<float *>(attributes));
+    return check_launch("rf_pack_attributes");
+}
+
+int rf_pack_attributes_backward(int sh_degree, uint32_t num_points, const float *density,
+                                float activation_scale, const float *attr_grad, float *att_dc_grad,
+                                float *att_sh_grad, float *density_grad, void *stream) {
+    g_err[0] = 0;
+    const uint32_t A = attribute_dim(sh_degree);
+    if (A == 0) return fail(RF_ERR_INVALID_ARGUMENT, "Unsupported SH degree");
+    if (num_points == 0) return RF_OK;
+    if (!density || !attr_grad || !att_dc_grad || !density_grad || (A > 4 && !att_sh_grad))
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_pack_attributes_backward: null pointer");
+    const size_t total = (size_t)num_points * A;
+    hipLaunchKernelGGL(pack_attributes_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), density, activation_scale, num_points, A, attr_grad,
+                       att_dc_grad, att_sh_grad, density_grad);
+    return check_launch("rf_pack_attributes_backward");
+}
+
+int rf_nearest_point(const float *points, uint32_t num_points, const float *queries, uint32_t num_queries,
+                     uint32_t *indices, void *scratch, void *stream) {
+    g_err[0] = 0;
+    if (num_queries == 0) return RF_OK;
+    if (num_points == 0) return fail(RF_ERR_INVALID_ARGUMENT, "rf_nearest_point: no points");
+    if (!points || !queries || !indices || !scratch)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_nearest_point: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long *best = static_cast<unsigned long long *>(scratch);
+    (void)hipMemsetAsync(best, 0xFF, (size_t)num_queries * 8, s);
+    const uint32_t per_block = 256u * kNnPerThread;
+    hipLaunchKernelGGL(nearest_point_kernel, dim3((num_points + per_block - 1u) / per_block), dim3(256), 0, s,
+                       points, num_points, queries, num_queries, best);
+    hipLaunchKernelGGL(nearest_point_finish_kernel, dim3((num_queries + 255u) / 256u), dim3(256), 0, s, best,
+                       num_queries, indices);
+    return check_launch("rf_nearest_point");
+}
+
+int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_t *point_adjacency,
+                         const uint32_t *point_adjacency_offsets, uint32_t *indices, float *cell_radius,
+                         void *stream) {
+    g_err[0] = 0;
+    if (num_points == 0) return RF_OK;
+    if (!points || !point_adjacency || !point_adjacency_offsets || !indices || !cell_radius)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_farthest_neighbor: null pointer");
+    hipLaunchKernelGGL(farthest_neighbor_kernel, dim3((num_points + 255u) / 256u), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), points, point_adjacency, point_adjacency_offsets,
+                       num_points, indices, cell_radius);
+    return check_launch("rf_farthest_neighbor");
+}
+
+}  // extern "C"

@@ -113,10 +113,15 @@ def build_aabb_tree(points: torch.Tensor) -> torch.Tensor:
 
 
 def nn(points: torch.Tensor, tree: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
-    """Index of the nearest point for every query (exact), uint32, shape queries.shape[:-1]."""
+    """Index of the nearest point for every query (exact), uint32, shape queries.shape[:-1].
+    float32 CUDA tensors go to the HIP kernel (scene_ops.nearest_point); CPU tensors, which the
+    reference also serves (nn_cpu, aabb_tree.cu:417-478), to the torch restatement below."""
     del tree
     if points.dtype != queries.dtype:
         raise RuntimeError("points and queries must have the same dtype")
+    if points.is_cuda and points.dtype == torch.float32:
+        from . import scene_ops
+        return scene_ops.nearest_point(points, queries.to(points.device)).to(queries.device)
     q = queries.reshape(-1, 3).to(points.device)
     out = torch.empty(q.size(0), dtype=torch.int64, device=points.device)
     p = points.detach().double()
@@ -130,6 +135,9 @@ def nn(points: torch.Tensor, tree: torch.Tensor, queries: torch.Tensor) -> torch
 def farthest_neighbor(points: torch.Tensor, point_adjacency: torch.Tensor,
                       point_adjacency_offsets: torch.Tensor):
     """(index of the farthest Delaunay neighbour, mean half-distance to the neighbours)."""
+    if points.is_cuda and points.dtype == torch.float32 and point_adjacency.dtype == torch.uint32:
+        from . import scene_ops
+        return scene_ops.farthest_neighbor(points, point_adjacency, point_adjacency_offsets)
     n = points.size(0)
     off = point_adjacency_offsets.to(torch.int64)
     adj = point_adjacency.to(torch.int64)

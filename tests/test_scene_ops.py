@@ -1,0 +1,189 @@
+"""Scene-side operators: attribute packing, entry-cell lookup, farthest neighbour.
+
+CPU part: the numpy checker (oracle/scene_ops_ref.py) is pinned to torch evaluating the reference's
+own expression (scene.py:202-217).  GPU part: the HIP kernels, through the C-ABI, against the checker.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import scene_ops_ref as R
+from radfoam_amd import foam
+
+
+def _scene_params(n, degree, seed, spread=1.0):
+    rng = np.random.default_rng(seed)
+    att_dc = rng.normal(0, 0.3, (n, 3)).astype(np.float32)
+    att_sh = rng.normal(0, 0.3, (n, 3 * ((degree + 1) ** 2 - 1))).astype(np.float32)
+    # raw densities covering all three softplus regimes: exp underflow, the knee, the linear branch
+    density = (rng.normal(0, 1.0, (n, 1)) * spread).astype(np.float32)
+    density[: min(n, 8), 0] = [-30.0, -9.0, -2.0, -0.1, 0.0, 0.3, 1.9999, 2.5][: min(n, 8)]
+    return att_dc, att_sh, density
+
+
+def _reference_expression(att_dc, att_sh, density, scale, dtype):
+    """RadFoamScene.get_trace_data, scene.py:202-217, verbatim in torch."""
+    primal_density = scale * F.softplus(density, beta=10)
+    primal_attributes = torch.cat([att_dc, att_sh], dim=-1)
+    return torch.cat([primal_attributes, primal_density], dim=-1).to(dtype)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+def test_checker_matches_reference_expression(degree):
+    dc, sh, dn = _scene_params(257, degree, 3 + degree, spread=1.5)
+    scale = 1.7
+    want = _reference_expression(torch.from_numpy(dc), torch.from_numpy(sh), torch.from_numpy(dn), scale,
+                                 torch.float32).numpy()
+    got = R.pack_attributes(dc, sh, dn, scale)
+    assert got.shape == (257, 1 + 3 * (degree + 1) ** 2)
+    np.testing.assert_array_equal(got[:, :-1], want[:, :-1])
+    np.testing.assert_allclose(got[:, -1], want[:, -1], rtol=3e-7, atol=1e-30)
+    # backward: autograd of the same expression
+    t = [torch.from_numpy(a.copy()).requires_grad_(True) for a in (dc, sh, dn)]
+    g = np.random.default_rng(9).normal(0, 1, want.shape).astype(np.float32)
+    _reference_expression(t[0], t[1], t[2], scale, torch.float32).backward(torch.from_numpy(g))
+    d_dc, d_sh, d_dn = R.pack_attributes_backward(dn, scale, g)
+    np.testing.assert_array_equal(d_dc, t[0].grad.numpy())
+    np.testing.assert_array_equal(d_sh, t[1].grad.numpy())
+    np.testing.assert_allclose(d_dn, t[2].grad.numpy(), rtol=3e-6, atol=1e-30)
+
+
+def test_checker_nearest_and_farthest_small():
+    fm = foam.make_synthetic_foam(600, 0, 21)
+    p = fm["points"]
+    q = np.array([[0.1, -0.2, 0.3], [5.0, 5.0, 5.0], p[17]], dtype=np.float32)
+    idx = R.nearest_point(p, q)
+    d = ((p.astype(np.float64)[None] - q.astype(np.float64)[:, None]) ** 2).sum(-1)
+    np.testing.assert_array_equal(idx, d.argmin(1).astype(np.uint32))
+    assert idx[2] == 17
+    far, radius = R.farthest_neighbor(p, fm["point_adjacency"], fm["point_adjacency_offsets"])
+    from radfoam_amd import shims
+    far_t, radius_t = shims.farthest_neighbor(torch.from_numpy(p), torch.from_numpy(fm["point_adjacency"]),
+                                              torch.from_numpy(fm["point_adjacency_offsets"]))
+    np.testing.assert_array_equal(far, far_t.numpy())
+    np.testing.assert_allclose(radius, radius_t.numpy(), rtol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+
+def _cuda(a):
+    return torch.from_numpy(a).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_pack_attributes_forward(degree, dtype):
+    import radfoam
+    dc, sh, dn = _scene_params(10_007, degree, 40 + degree, spread=1.5)
+    scale = 0.83
+    out = radfoam.pack_attributes(_cuda(dc), _cuda(sh), _cuda(dn), scale, dtype)
+    assert out.dtype == dtype and out.shape == (10_007, 1 + 3 * (degree + 1) ** 2)
+    want = R.pack_attributes(dc, sh, dn, scale)
+    got = out.float().cpu().numpy()
+    if dtype == torch.float32:
+        np.testing.assert_array_equal(got[:, :-1], want[:, :-1])               # pure copies
+        np.testing.assert_allclose(got[:, -1], want[:, -1], rtol=4e-7, atol=1e-30)   # <= 2 ulp softplus
+    else:
+        want16 = want.astype(np.float16).astype(np.float32)
+        np.testing.assert_array_equal(got[:, :-1], want16[:, :-1])
+        np.testing.assert_allclose(got[:, -1], want16[:, -1], rtol=1e-3)       # one half ulp at rounding ties
+    # and against torch evaluating the reference expression on the device
+    ref = _reference_expression(_cuda(dc), _cuda(sh), _cuda(dn), scale, dtype).float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-3 if dtype == torch.float16 else 1e-6, atol=1e-30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("degree", [0, 2, 3])
+def test_pack_attributes_backward(degree):
+    import radfoam
+    dc, sh, dn = _scene_params(5_003, degree, 50 + degree, spread=1.5)
+    scale = 1.3
+    t = [_cuda(a).requires_grad_(True) for a in (dc, sh, dn)]
+    out = radfoam.pack_attributes(t[0], t[1], t[2], scale, torch.float32)
+    g = np.random.default_rng(5).normal(0, 1, tuple(out.shape)).astype(np.float32)
+    out.backward(_cuda(g))
+    d_dc, d_sh, d_dn = R.pack_attributes_backward(dn, scale, g)
+    np.testing.assert_array_equal(t[0].grad.cpu().numpy(), d_dc)
+    np.testing.assert_array_equal(t[1].grad.cpu().numpy(), d_sh)
+    np.testing.assert_allclose(t[2].grad.cpu().numpy(), d_dn, rtol=3e-6, atol=1e-30)
+
+
+@pytest.mark.gpu
+def test_pack_attributes_feeds_the_tracer_and_backpropagates():
+    """get_trace_data -> TraceRays -> loss.backward through the fused packing, against the torch expression."""
+    import radfoam
+    from radfoam_amd.render import TraceRays
+    fm = foam.make_synthetic_foam(3000, 1, 31)
+    n = fm["points"].shape[0]
+    dc, sh, dn = _scene_params(n, 1, 7, spread=0.4)
+    dn += 0.2
+    cam = foam.default_camera(40, 30)
+    rays = _cuda(foam.camera_rays(cam))
+    start = torch.full(rays.shape[:-1], foam.nearest_point(fm["points"], cam["position"]),
+                       dtype=torch.int64).to(torch.uint32).cuda()
+    pts, adj, off = _cuda(fm["points"]), _cuda(fm["point_adjacency"]), _cuda(fm["point_adjacency_offsets"])
+    pipe = radfoam.create_pipeline(1, torch.float32)
+    grads = []
+    for fused in (True, False):
+        t = [_cuda(a).requires_grad_(True) for a in (dc, sh, dn)]
+        attrs = radfoam.pack_attributes(t[0], t[1], t[2], 2.0) if fused else \
+            _reference_expression(t[0], t[1], t[2], 2.0, torch.float32)
+        rgba, *_ = TraceRays.apply(pipe, pts, attrs, adj, off, rays, start, None, False)
+        rgba[..., :3].square().sum().backward()
+        grads.append([x.grad.cpu().numpy() for x in t])
+    for a, b in zip(*grads):
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_pack_attributes_argument_errors():
+    import radfoam
+    dc, sh, dn = _scene_params(16, 2, 1)
+    with pytest.raises(RuntimeError):
+        radfoam.pack_attributes(torch.from_numpy(dc), _cuda(sh), _cuda(dn))          # CPU tensor
+    with pytest.raises(RuntimeError):
+        radfoam.pack_attributes(_cuda(dc), _cuda(sh[:, :5].copy()), _cuda(dn))       # not an SH width
+    with pytest.raises(RuntimeError):
+        radfoam.pack_attributes(_cuda(dc), _cuda(sh), _cuda(dn), 1.0, torch.bfloat16)
+    empty = radfoam.pack_attributes(_cuda(dc[:0]), _cuda(sh[:0]), _cuda(dn[:0]))
+    assert empty.shape == (0, 28)
+
+
+@pytest.mark.gpu
+def test_nearest_point_matches_checker():
+    import radfoam
+    fm = foam.make_synthetic_foam(200_000, 0, 11, cache_dir=foam.default_cache_dir())
+    p = fm["points"]
+    rng = np.random.default_rng(2)
+    q = np.concatenate([rng.uniform(-1, 1, (13, 3)), [[0.0, 0.0, -3.0], [40.0, -7.0, 2.0]], p[[5, 199_999]]]
+                       ).astype(np.float32)
+    got = radfoam.nn(_cuda(p), radfoam.build_aabb_tree(_cuda(p)), _cuda(q))
+    assert got.dtype == torch.uint32 and got.shape == (17,)
+    want = R.nearest_point(p, q)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert got[-2] == 5 and got[-1] == 199_999
+    # batch shape is preserved, an empty batch is fine
+    assert radfoam.nn(_cuda(p), None, _cuda(q[:6].reshape(2, 3, 3))).shape == (2, 3)
+    assert radfoam.nn(_cuda(p), None, _cuda(q[:0])).shape == (0,)
+
+
+@pytest.mark.gpu
+def test_nearest_point_ties_take_the_lowest_index():
+    import radfoam
+    p = np.zeros((5000, 3), dtype=np.float32)
+    p[:, 0] = np.arange(5000) % 7          # many exact duplicates
+    got = radfoam.nn(_cuda(p), None, _cuda(np.array([[3.2, 0, 0], [100.0, 0, 0]], dtype=np.float32)))
+    assert got.cpu().tolist() == [3, 6]
+
+
+@pytest.mark.gpu
+def test_farthest_neighbor_matches_checker():
+    import radfoam
+    fm = foam.make_synthetic_foam(4000, 0, 13)
+    far, radius = radfoam.farthest_neighbor(_cuda(fm["points"]), _cuda(fm["point_adjacency"]),
+                                            _cuda(fm["point_adjacency_offsets"]))
+    want_far, want_radius = R.farthest_neighbor(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    np.testing.assert_array_equal(far.cpu().numpy(), want_far)
+    np.testing.assert_allclose(radius.cpu().numpy(), want_radius, rtol=1e-6)
