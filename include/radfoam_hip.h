@@ -193,6 +193,17 @@ int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_
                          const uint32_t *point_adjacency_offsets, uint32_t *indices,
                          float *cell_radius, void *stream);
 
+/* CSR point adjacency from tetrahedra (find_adjacency, src/delaunay/delaunay.cu:140-229): tets is
+ * uint32[num_tets][4]; writes point_adjacency_offsets[num_points + 1], the neighbours of every
+ * point in ascending order into point_adjacency (capacity 12 * num_tets entries) and their number
+ * into the DEVICE word *point_adjacency_size.  Tets with an index >= num_points or a repeated
+ * vertex contribute nothing. */
+size_t rf_adjacency_workspace_bytes(uint32_t num_tets);
+int rf_build_adjacency(const uint32_t *tets, uint32_t num_tets, uint32_t num_points,
+                       uint32_t *point_adjacency, uint32_t *point_adjacency_offsets,
+                       uint32_t *point_adjacency_size, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

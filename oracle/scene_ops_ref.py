@@ -5,6 +5,7 @@ oracle/): the checker for radfoam_amd/csrc/rf_scene_ops.hip.
                               get_trace_data): cat[att_dc, att_sh, scale * softplus(density, beta=10)]
   nearest_point               radfoam.nn semantics (triangulation_bindings.cpp:142-181): nearest by distance
   farthest_neighbor           src/delaunay/triangulation_ops.cu:9-44
+  adjacency_from_tets         find_adjacency, src/delaunay/delaunay.cu:140-229
 
 Pinned in tests/test_scene_ops.py against torch evaluating the reference's own expression
 (F.softplus(beta=10), torch.cat, autograd) on the CPU.
@@ -94,3 +95,19 @@ def farthest_neighbor(points, adjacency, offsets):
                 idx[i] = adj[f]
         radius[i] = s / np.float32(e - b) if e > b else np.float32(np.nan)
     return idx, radius
+
+
+def adjacency_from_tets(tets, num_points):
+    """CSR (adjacency, offsets) with ascending neighbour lists: the unique directed edges of all
+    tetrahedra, sorted by (source, target).  Tets with an index >= num_points or a repeated vertex
+    are ignored, as rf_build_adjacency does."""
+    t = np.asarray(tets, dtype=np.int64).reshape(-1, 4)
+    pairs = []
+    for a in range(4):
+        for b in range(4):
+            if a != b:
+                ok = (t[:, a] < num_points) & (t[:, b] < num_points) & (t[:, a] != t[:, b])
+                pairs.append(np.stack([t[ok, a], t[ok, b]], axis=1))
+    e = np.unique(np.concatenate(pairs, axis=0), axis=0) if pairs else np.zeros((0, 2), np.int64)
+    offsets = np.searchsorted(e[:, 0], np.arange(num_points + 1), side="left").astype(np.uint32)
+    return e[:, 1].astype(np.uint32), offsets

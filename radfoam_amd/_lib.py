@@ -77,6 +77,8 @@ SYMBOLS = {
     "rf_pack_attributes_backward": (_INT, [_INT, _U32, _P, C.c_float, _P, _P, _P, _P, _P]),
     "rf_nearest_point": (_INT, [_P, _U32, _P, _U32, _P, _P, _P]),
     "rf_farthest_neighbor": (_INT, [_P, _U32, _P, _P, _P, _P, _P]),
+    "rf_adjacency_workspace_bytes": (C.c_size_t, [_U32]),
+    "rf_build_adjacency": (_INT, [_P, _U32, _U32, _P, _P, _P, _P, C.c_size_t, _P]),
     "rf_trace_benchmark": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _P,
                                   C.POINTER(Camera), _P, _P, C.POINTER(LaunchOpts), _P]),
 }

@@ -5,6 +5,7 @@
                      as one kernel, differentiable (torch.autograd.Function)
   nearest_point      radfoam.nn for camera positions (triangulation_bindings.cpp:142-181)
   farthest_neighbor  radfoam.farthest_neighbor (triangulation_bindings.cpp:183-217)
+  adjacency_from_tets  find_adjacency (src/delaunay/delaunay.cu:140-229): tetrahedra -> CSR adjacency
 
 All three take CUDA (HIP) tensors and run behind the C-ABI of include/radfoam_hip.h; there is no
 CPU path in this module (radfoam_amd/shims.py keeps torch restatements for CPU tensors, which the
@@ -122,3 +123,30 @@ def farthest_neighbor(points: torch.Tensor, point_adjacency: torch.Tensor,
                                               _stream(p.device))
     _lib.check(rc)
     return idx.view(torch.uint32), radius
+
+
+def adjacency_from_tets(tets: torch.Tensor, num_points: int):
+    """(point_adjacency uint32[E], point_adjacency_offsets uint32[N+1]) of the triangulation whose
+    tetrahedra are ``tets`` (uint32 or int32/int64 [T,4], CUDA): every point's Delaunay neighbours in
+    ascending order, as the reference's find_adjacency produces them.  Synchronises once to learn E
+    (the reference does the same, delaunay.cu:180-184)."""
+    if not tets.is_cuda or tets.dim() != 2 or tets.size(1) != 4:
+        raise RuntimeError("tets must be a [T,4] CUDA tensor")
+    if tets.dtype in (torch.int64, torch.int32):
+        t = tets.to(torch.int32).contiguous()
+    elif tets.dtype == torch.uint32:
+        t = tets.contiguous()
+    else:
+        raise RuntimeError("tets must have an integer dtype")
+    dev, nt = t.device, t.size(0)
+    lib = _lib.load()
+    adj = torch.empty(max(12 * nt, 1), dtype=torch.int32, device=dev)
+    off = torch.empty(int(num_points) + 1, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(int(lib.rf_adjacency_workspace_bytes(nt)), 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.rf_build_adjacency(_ptr(t), nt, int(num_points), _ptr(adj), _ptr(off), _ptr(count), _ptr(ws),
+                                    ws.numel(), _stream(dev))
+    _lib.check(rc)
+    e = int(count.item())
+    return adj[:e].clone().view(torch.uint32), off.view(torch.uint32)

@@ -54,11 +54,18 @@ class Triangulation:
         n = pts_sorted.shape[0]
         if len(indptr) != n + 1 or (np.diff(indptr) == 0).any():
             raise TriangulationFailedError("triangulation dropped points (duplicates or degenerate input)")
-        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
-        order = np.lexsort((np.asarray(indices, dtype=np.int64), rows))
-        self._adjacency = np.asarray(indices, dtype=np.int64)[order].astype(np.uint32)
-        self._offsets = np.asarray(indptr, dtype=np.int64).astype(np.uint32)
         self._tets = np.ascontiguousarray(tri.simplices.astype(np.uint32))
+        if self._device.type == "cuda":
+            # tetrahedra -> CSR on the GPU (find_adjacency, delaunay.cu:140-229)
+            from . import scene_ops
+            adj, off = scene_ops.adjacency_from_tets(torch.from_numpy(self._tets.view(np.int32)).to(self._device), n)
+            self._adjacency = adj.cpu().numpy()
+            self._offsets = off.cpu().numpy()
+        else:
+            rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr))
+            order = np.lexsort((np.asarray(indices, dtype=np.int64), rows))
+            self._adjacency = np.asarray(indices, dtype=np.int64)[order].astype(np.uint32)
+            self._offsets = np.asarray(indptr, dtype=np.int64).astype(np.uint32)
         self._tet_adjacency = np.ascontiguousarray(tri.neighbors.astype(np.int64).astype(np.uint32))
         self._vert_to_tet = np.ascontiguousarray(tri.vertex_to_simplex.astype(np.uint32))
 

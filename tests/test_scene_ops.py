@@ -65,6 +65,20 @@ def test_checker_nearest_and_farthest_small():
     np.testing.assert_allclose(radius, radius_t.numpy(), rtol=2e-6)
 
 
+def test_checker_adjacency_from_tets_matches_qhull_neighbours():
+    from scipy.spatial import Delaunay
+    pts = np.random.default_rng(4).uniform(-1, 1, (500, 3))
+    tri = Delaunay(pts)
+    adj, off = R.adjacency_from_tets(tri.simplices, 500)
+    indptr, indices = tri.vertex_neighbor_vertices
+    np.testing.assert_array_equal(off, indptr.astype(np.uint32))
+    for i in range(500):
+        np.testing.assert_array_equal(adj[off[i]:off[i + 1]], np.sort(indices[indptr[i]:indptr[i + 1]]))
+    # the same CSR the synthetic foams (and so every tracer test) are built with
+    fm = foam.make_synthetic_foam(700, 0, 5)
+    assert (np.diff(fm["point_adjacency_offsets"].astype(np.int64)) > 0).all()
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 
 def _cuda(a):
@@ -187,3 +201,35 @@ def test_farthest_neighbor_matches_checker():
     want_far, want_radius = R.farthest_neighbor(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"])
     np.testing.assert_array_equal(far.cpu().numpy(), want_far)
     np.testing.assert_allclose(radius.cpu().numpy(), want_radius, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_adjacency_from_tets_matches_checker():
+    from scipy.spatial import Delaunay
+    from radfoam_amd import scene_ops
+    pts = np.random.default_rng(8).uniform(-1, 1, (20_000, 3))
+    tets = Delaunay(pts).simplices.astype(np.int32)
+    adj, off = scene_ops.adjacency_from_tets(torch.from_numpy(tets).cuda(), 20_000)
+    want_adj, want_off = R.adjacency_from_tets(tets, 20_000)
+    assert adj.dtype == torch.uint32 and off.dtype == torch.uint32
+    np.testing.assert_array_equal(off.cpu().numpy(), want_off)
+    np.testing.assert_array_equal(adj.cpu().numpy(), want_adj)
+    # junk tets are ignored, unreferenced points get empty ranges, no tets at all is fine
+    bad = np.concatenate([tets[:100], [[0, 0, 1, 2], [5, 6, 7, 99_999_999 % 2**31]]]).astype(np.int32)
+    adj2, off2 = scene_ops.adjacency_from_tets(torch.from_numpy(bad).cuda(), 20_010)
+    w_adj2, w_off2 = R.adjacency_from_tets(bad, 20_010)
+    np.testing.assert_array_equal(off2.cpu().numpy(), w_off2)
+    np.testing.assert_array_equal(adj2.cpu().numpy(), w_adj2)
+    adj3, off3 = scene_ops.adjacency_from_tets(torch.zeros((0, 4), dtype=torch.int32).cuda(), 7)
+    assert adj3.numel() == 0 and off3.cpu().tolist() == [0] * 8
+
+
+@pytest.mark.gpu
+def test_triangulation_on_gpu_builds_the_same_csr():
+    import radfoam
+    pts = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (3000, 3)).astype(np.float32))
+    cpu = radfoam.Triangulation(pts)
+    gpu = radfoam.Triangulation(pts.cuda())
+    assert gpu.point_adjacency().is_cuda
+    np.testing.assert_array_equal(gpu.point_adjacency().cpu().numpy(), cpu.point_adjacency().numpy())
+    np.testing.assert_array_equal(gpu.point_adjacency_offsets().cpu().numpy(), cpu.point_adjacency_offsets().numpy())
