@@ -59,6 +59,10 @@ typedef struct rf_launch_opts {
     size_t workspace_bytes;
     uint32_t foam_prepared;   /* 1: workspace already holds rf_prepare_foam() output for these inputs */
                               /*   (for rf_trace_benchmark: prepared WITH the same adjacent_diff)     */
+                              /* 2: it holds the output for the same ADJACENCY, but points and/or     */
+                              /*   attributes changed: only cells and face offsets are repacked       */
+                              /*   (rf_trace_forward / rf_trace_backward; what an optimiser step      */
+                              /*   between two triangulation rebuilds needs)                          */
     uint32_t image_width;     /* rays form a row-major [image_height, image_width] grid: lets a wave  */
     uint32_t image_height;    /*   own an 8x8 pixel tile.  0,0 = treat rays as a flat list            */
     uint32_t backward_mode;   /* rf_trace_backward only: 0 = auto, 1 = per-lane atomics, 2 = wave     */
@@ -162,6 +166,13 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
                        const uint32_t *point_adjacency_offsets, const void *adjacent_diff,
                        const rf_camera *camera, const uint32_t *start_point_index,
                        uint32_t *ray_rgba, const rf_launch_opts *opts, void *stream);
+
+/* The part of rf_prepare_foam that depends on points / attributes: rewrites cell records, fp16 face
+ * offsets and SH rows of a workspace whose adjacency-derived part (padded offsets, links) was
+ * packed by rf_prepare_foam for the same point_adjacency / offsets (without adjacent_diff). */
+int rf_prepare_foam_geometry(int sh_degree, int attr_type, uint32_t num_points, const float *points,
+                             const void *attributes, uint32_t point_adjacency_size, void *workspace,
+                             size_t workspace_bytes, void *stream);
 
 /* ---- the callers on either side of the tracer -------------------------------- */
 

@@ -68,6 +68,7 @@ SYMBOLS = {
     "rf_workspace_bytes": (C.c_size_t, [_U32, _U32, _INT, _INT]),
     "rf_build_adjacent_diff": (_INT, [_P, _U32, _U32, _P, _P, _P, _P]),
     "rf_prepare_foam": (_INT, [_INT, _INT, _U32, _P, _P, _U32, _P, _P, _P, _P, C.c_size_t, _P]),
+    "rf_prepare_foam_geometry": (_INT, [_INT, _INT, _U32, _P, _P, _U32, _P, C.c_size_t, _P]),
     "rf_trace_forward": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _U32,
                                 _P, _P, _U32, _P, _P, _P, _P, _P, _P, C.POINTER(LaunchOpts), _P]),
     "rf_trace_backward": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _U32,

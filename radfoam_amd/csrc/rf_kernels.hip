@@ -1578,6 +1578,51 @@ __global__ __launch_bounds__(256) void prepare_foam_kernel(
     }
 }
 
+// Geometry-only repack: the padded offsets and the links of a workspace depend on the adjacency
+// alone, so while the triangulation is unchanged (every optimiser step between two rebuilds) only
+// the cell records and the fp16 face offsets are rewritten.  Same ownership scheme as above; the
+// neighbour of an entry comes from its link (count 0 marks a padding entry).
+template <bool HALF>
+__global__ __launch_bounds__(256) void prepare_geometry_kernel(
+    const float *__restrict__ points, const void *__restrict__ attributes, uint32_t attr_dim,
+    uint32_t num_points, const uint32_t *__restrict__ poff, const Link *__restrict__ link,
+    float4 *__restrict__ cells, uint16_t *__restrict__ geo) {
+    __shared__ uint32_t s_off[4][66];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t c0 = (blockIdx.x * 4u + wave) * 64u;
+    if (c0 >= num_points) return;
+    const uint32_t ncells = (num_points - c0 < 64u) ? num_points - c0 : 64u;
+    uint32_t *off = s_off[wave];
+    if (lane <= ncells) off[lane] = poff[c0 + lane];
+    if (lane == 0u) off[ncells] = poff[c0 + ncells];
+    if (lane < ncells) {
+        const uint32_t i = c0 + lane;
+        float s = load_attr_scalar<HALF>(attributes, (size_t)i * attr_dim + attr_dim - 1);
+        cells[i] = make_float4(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2], s);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t f_begin = off[0], f_end = off[ncells];
+    for (uint32_t f = f_begin + lane; f < f_end; f += 64u) {
+        uint32_t lo = 0, hi = ncells;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] <= f) lo = mid; else hi = mid;
+        }
+        const Link lk = link[f];
+        uint2 d = make_uint2(0u, 0u);
+        if (lk.count != 0u) {
+            const uint32_t i = c0 + lo, q = lk.nbr;
+            const float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
+            const float qx = points[3 * (size_t)q], qy = points[3 * (size_t)q + 1], qz = points[3 * (size_t)q + 2];
+            d = pack_diff(qx - px, qy - py, qz - pz);
+        }
+        uint16_t *g = geo + (size_t)(f >> 2) * 12u + (f & 3u);
+        g[0] = (uint16_t)(d.x & 0xFFFFu);
+        g[4] = (uint16_t)(d.x >> 16);
+        g[8] = (uint16_t)(d.y & 0xFFFFu);
+    }
+}
+
 // plain half4 table of the reference (pipeline.cu:546-568)
 __global__ __launch_bounds__(256) void adjacent_diff_kernel(const float *__restrict__ points,
                                                             uint32_t num_points,
@@ -1629,7 +1674,7 @@ static FoamView make_view(const FoamLayout &L, void *ws, const void *attributes,
 static int prepare_impl(int sh_degree, int attr_type, uint32_t num_points, const float *points,
                         const void *attributes, uint32_t adj_size, const uint32_t *adj,
                         const uint32_t *offsets, const void *ext_diff, void *ws, size_t ws_bytes,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool topology_valid = false) {
     const bool half = attr_type == RF_ATTR_FLOAT16;
     FoamLayout L = foam_layout(num_points, adj_size, sh_degree, half);
     if (!ws || ws_bytes < L.total) return fail(RF_ERR_WORKSPACE, "workspace missing or smaller than rf_workspace_bytes()");
@@ -1642,18 +1687,27 @@ static int prepare_impl(int sh_degree, int attr_type, uint32_t num_points, const
     uint32_t *sums = reinterpret_cast<uint32_t *>(base + L.scan_off);
     const uint32_t A = attribute_dim(sh_degree);
     dim3 block(256);
-    // padded offsets; chunks cover cells 0..num_points inclusive (the last entry is the total)
-    const uint32_t nchunks = num_points / kScanChunk + 1u;
-    hipLaunchKernelGGL(padded_chunk_sums_kernel, dim3(nchunks), block, 0, stream, offsets, num_points, sums);
-    hipLaunchKernelGGL(padded_scan_sums_kernel, dim3(1), block, 0, stream, sums, nchunks);
-    hipLaunchKernelGGL(padded_offsets_kernel, dim3(nchunks), block, 0, stream, offsets, num_points, sums, poff);
     dim3 grid((num_points + 255u) / 256u);   // 4 waves x 64 cells per block
-    if (half)
-        hipLaunchKernelGGL(prepare_foam_kernel<true>, grid, block, 0, stream, points, attributes, A, num_points,
-                           adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link);
-    else
-        hipLaunchKernelGGL(prepare_foam_kernel<false>, grid, block, 0, stream, points, attributes, A, num_points,
-                           adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link);
+    if (topology_valid && !ext_diff) {
+        if (half)
+            hipLaunchKernelGGL(prepare_geometry_kernel<true>, grid, block, 0, stream, points, attributes, A,
+                               num_points, poff, link, cells, geo);
+        else
+            hipLaunchKernelGGL(prepare_geometry_kernel<false>, grid, block, 0, stream, points, attributes, A,
+                               num_points, poff, link, cells, geo);
+    } else {
+        // padded offsets; chunks cover cells 0..num_points inclusive (the last entry is the total)
+        const uint32_t nchunks = num_points / kScanChunk + 1u;
+        hipLaunchKernelGGL(padded_chunk_sums_kernel, dim3(nchunks), block, 0, stream, offsets, num_points, sums);
+        hipLaunchKernelGGL(padded_scan_sums_kernel, dim3(1), block, 0, stream, sums, nchunks);
+        hipLaunchKernelGGL(padded_offsets_kernel, dim3(nchunks), block, 0, stream, offsets, num_points, sums, poff);
+        if (half)
+            hipLaunchKernelGGL(prepare_foam_kernel<true>, grid, block, 0, stream, points, attributes, A, num_points,
+                               adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link);
+        else
+            hipLaunchKernelGGL(prepare_foam_kernel<false>, grid, block, 0, stream, points, attributes, A, num_points,
+                               adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link);
+    }
     if (L.sh_repacked) {
         size_t total = (size_t)num_points * L.sh_stride;
         dim3 g2((unsigned)((total + 255) / 256));
@@ -1793,6 +1847,18 @@ int rf_prepare_foam(int sh_degree, int attr_type, uint32_t num_points, const flo
                         workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
+int rf_prepare_foam_geometry(int sh_degree, int attr_type, uint32_t num_points, const float *points,
+                             const void *attributes, uint32_t point_adjacency_size, void *workspace,
+                             size_t workspace_bytes, void *stream) {
+    g_err[0] = 0;
+    if (!valid_instance(sh_degree, attr_type))
+        return fail(RF_ERR_INVALID_ARGUMENT, "Unsupported SH degree or attribute type");
+    if (num_points && (!points || !attributes))
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_prepare_foam_geometry: null pointer");
+    return prepare_impl(sh_degree, attr_type, num_points, points, attributes, point_adjacency_size, nullptr,
+                        nullptr, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream), true);
+}
+
 int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *settings,
                      uint32_t num_points, const float *points, const void *attributes,
                      uint32_t point_adjacency_size, const uint32_t *point_adjacency,
@@ -1816,10 +1882,10 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
     if (!opts->workspace || opts->workspace_bytes < L.total)
         return fail(RF_ERR_WORKSPACE, "workspace missing or smaller than rf_workspace_bytes()");
-    if (!opts->foam_prepared) {
+    if (opts->foam_prepared != 1u) {
         int rc = prepare_impl(sh_degree, attr_type, num_points, points, attributes, point_adjacency_size,
                               point_adjacency, point_adjacency_offsets, nullptr, opts->workspace,
-                              opts->workspace_bytes, s);
+                              opts->workspace_bytes, s, opts->foam_prepared == 2u);
         if (rc != RF_OK) return rc;
     }
     FwdParams p{};
@@ -1874,10 +1940,10 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
     if (!opts->workspace || opts->workspace_bytes < L.total)
         return fail(RF_ERR_WORKSPACE, "workspace missing or smaller than rf_workspace_bytes()");
-    if (!opts->foam_prepared) {
+    if (opts->foam_prepared != 1u) {
         int rc = prepare_impl(sh_degree, attr_type, num_points, points, attributes, point_adjacency_size,
                               point_adjacency, point_adjacency_offsets, nullptr, opts->workspace,
-                              opts->workspace_bytes, s);
+                              opts->workspace_bytes, s, opts->foam_prepared == 2u);
         if (rc != RF_OK) return rc;
     }
     BwdParams p{};

@@ -66,12 +66,18 @@ class _FoamCache:
     """One packed foam per Pipeline, keyed on the identity + version of the input tensors
     (points, attributes, adjacency, offsets and, for trace_benchmark, the caller's half table).
 
+    Two levels: ``lookup`` -- everything unchanged, the workspace is used as it is; ``lookup_topology``
+    -- adjacency and offsets unchanged (the triangulation was not rebuilt) but points / attributes
+    were updated, e.g. by an optimiser step: the padded offsets and links in the workspace are still
+    right and only cells and face offsets are repacked (rf_launch_opts.foam_prepared = 2).
+
     The entry keeps the input tensors alive, so their storage cannot be handed to a different
     tensor while the entry could still be matched.
     """
 
     def __init__(self):
         self.key = None
+        self.topo_key = None
         self.refs = None
         self.workspace = None
 
@@ -83,12 +89,29 @@ class _FoamCache:
     def lookup(self, tensors):
         return self.key is not None and self.key == self._key(tensors)
 
+    def lookup_topology(self, tensors):
+        """tensors = (points, attributes, adjacency, offsets, ext_diff)"""
+        if self.topo_key is None or tensors[4] is not None:
+            return False
+        n_key = (tuple(tensors[0].shape), tensors[0].device, tuple(tensors[1].shape), tensors[1].dtype)
+        return self.topo_key == (self._key(tensors[2:4]), n_key)
+
     def store(self, tensors):
         self.key = self._key(tensors)
         self.refs = tuple(tensors)
+        if tensors[4] is None:
+            n_key = (tuple(tensors[0].shape), tensors[0].device, tuple(tensors[1].shape), tensors[1].dtype)
+            self.topo_key = (self._key(tensors[2:4]), n_key)
+        else:   # packed from a caller's half table: not reusable by the differentiable path
+            self.topo_key = None
+
+    def invalidate_geometry(self):
+        """Forget the points / attributes the workspace was packed from (keeps the topology level)."""
+        self.key = None
 
     def clear(self):
         self.key = None
+        self.topo_key = None
         self.refs = None
 
 
@@ -198,15 +221,16 @@ class Pipeline:
         nbytes = int(self._lib.rf_workspace_bytes(n, e, self._sh_degree, self._attr_type))
         tensors = (points, attributes, adjacency, offsets, ext_diff)
         hit = self.cache_foam and self._cache.lookup(tensors)
+        topo = (not hit) and self.cache_foam and self._cache.lookup_topology(tensors)
         ws = self._cache.workspace
         if ws is None or ws.numel() < nbytes or ws.device != points.device:
             ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=points.device)
             self._cache.workspace = ws
-            hit = False
+            hit = topo = False
         opts = _lib.LaunchOpts()
         opts.workspace = ws.data_ptr()
         opts.workspace_bytes = ws.numel()
-        opts.foam_prepared = 1 if hit else 0
+        opts.foam_prepared = 1 if hit else (2 if topo else 0)
         opts.backward_mode = int(self.backward_mode)
         # rays given as an image [H, W, 6]: let a wave own an 8x8 pixel tile
         if len(rays_shape) == 3:
@@ -225,7 +249,13 @@ class Pipeline:
         adjacency_c, offsets_c = point_adjacency.contiguous(), point_adjacency_offsets.contiguous()
         self._validate_scene_data(points, attributes, point_adjacency, point_adjacency_offsets)
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, ())
-        if not opts.foam_prepared:
+        if opts.foam_prepared == 2:
+            with torch.cuda.device(points_c.device):
+                rc = self._lib.rf_prepare_foam_geometry(
+                    self._sh_degree, self._attr_type, points_c.size(0), _ptr(points_c), _ptr(attributes_c),
+                    adjacency_c.numel(), opts.workspace, opts.workspace_bytes, _stream_ptr(points_c.device))
+            _lib.check(rc)
+        elif not opts.foam_prepared:
             with torch.cuda.device(points_c.device):
                 rc = self._lib.rf_prepare_foam(
                     self._sh_degree, self._attr_type, points_c.size(0), _ptr(points_c), _ptr(attributes_c),

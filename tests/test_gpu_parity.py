@@ -253,6 +253,40 @@ def test_foam_cache_invalidation(foam_factory):
     assert not np.array_equal(got1["rgba"].numpy(), ref2["rgba"])
 
 
+@pytest.mark.parametrize("d", [1, 2])
+def test_geometry_only_repack_after_an_optimiser_step(foam_factory, d):
+    """points / attributes updated in place with the triangulation unchanged: the pipeline repacks
+    only cells and face offsets (foam_prepared = 2) and must give what a fresh full pack gives."""
+    fm = foam_factory(5000, d, 60 + d)
+    cam, rays, start = H.camera_setup(fm, 48, 40)
+    pipe = _pipeline(d)
+    _, (p, a, adj, off, r, s) = _run_forward(pipe, fm, rays, start)
+    rng = np.random.default_rng(3)
+    dp = (rng.normal(0, 2e-3, fm["points"].shape)).astype(np.float32)
+    da = (rng.normal(0, 5e-2, fm["attributes"].shape)).astype(np.float32)
+    da[:, -1] = 0.0
+    with torch.no_grad():
+        p += torch.from_numpy(dp).to(DEV)
+        a += torch.from_numpy(da).to(DEV)
+    opts = pipe._launch_opts(p, a, adj, off, r.shape)
+    assert opts.foam_prepared == 2
+    pipe._cache.invalidate_geometry()
+    out = pipe.trace_forward(p, a, adj, off, r, s)
+    pts2, att2 = fm["points"] + dp, fm["attributes"] + da
+    ref = O.trace_forward(d, pts2, att2, fm["point_adjacency"], fm["point_adjacency_offsets"], rays, start)
+    np.testing.assert_array_equal(out["rgba"].cpu().numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+    np.testing.assert_array_equal(out["num_intersections"].cpu().numpy().view(np.uint32), ref["num_intersections"])
+    # backward through the same (geometry-repacked) workspace and trail
+    g = torch.from_numpy(rng.normal(0, 1, out["rgba"].shape).astype(np.float32)).to(DEV)
+    res = pipe.trace_backward(p, a, adj, off, r, s, out["rgba"], g)
+    refb = O.trace_backward(d, pts2, att2, fm["point_adjacency"], fm["point_adjacency_offsets"], rays, start,
+                            ref["rgba"], g.cpu().numpy())
+    H.grad_close(res["points_grad"].cpu().numpy(), refb["points_grad"])
+    H.grad_close(res["attr_grad"].cpu().numpy(), refb["attr_grad"])
+    # a new adjacency tensor (a rebuilt triangulation) is packed from scratch
+    assert pipe._launch_opts(p, a, adj.clone(), off, r.shape).foam_prepared == 0
+
+
 def test_large_image_properties(foam_factory):
     """Bigger workload (not oracle-sized): size-independent properties."""
     d = 2
