@@ -1148,20 +1148,36 @@ struct CacheLayout {
 };
 
 // Flush rows to global memory (whole block, between barriers).  all == false: only rows whose
-// touch flag is clear; the flags of the others are cleared for the next epoch.
+// touch flag is clear; the flags of the others are cleared for the next epoch.  Wave w owns rows
+// [64w, 64w+64): one lane per row decides, then the rows to evict are written out two at a time
+// (one per half-wave, a lane per column: one coalesced row of atomics, zeros skipped).
 template <int NB>
 __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint8_t *touch, bool all,
                                             float *attr_grad, float *points_grad,
                                             unsigned long long *g_dbg = nullptr) {
     using L = CacheLayout<NB>;
     constexpr int A = 1 + 3 * NB;
-    const uint32_t half = threadIdx.x >> 5, col0 = threadIdx.x & 31u;
-    for (uint32_t r = half; r < (uint32_t)kCacheRows; r += (uint32_t)(kBlock / 32)) {
-        const uint32_t key = keys[r];
-        if (key == kNone) continue;
-        const bool evict = all || touch[r] == 0u;
-        if (evict) {
-#ifdef RF_EXPERIMENT_STATS
+    static_assert(kCacheRows == kBlock, "one lane per cache row");
+    const uint32_t lane = threadIdx.x & 63u, col0 = threadIdx.x & 31u, base = threadIdx.x & ~63u;
+    const uint32_t my_key = keys[threadIdx.x];
+    const bool occupied = my_key != kNone;
+    const bool evict = occupied && (all || touch[threadIdx.x] == (uint8_t)0);
+    if (occupied && !evict) touch[threadIdx.x] = (uint8_t)0;
+    if (evict) keys[threadIdx.x] = kNone;
+    unsigned long long todo = ballot(evict);
+    while (todo != 0ull) {
+        const uint32_t b0 = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        uint32_t b1 = 64u;
+        if (todo != 0ull) {
+            b1 = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+        }
+        const uint32_t mine = lane < 32u ? b0 : b1;
+        const uint32_t key = __shfl(my_key, (int)(mine & 63u), 64);
+        if (mine < 64u) {
+            const uint32_t r = base + mine;
+#ifdef RF_EXPERIMENT_TIMELINE
             if (col0 == 0u && g_dbg) atomicAdd(g_dbg + 0, 1ull);
 #endif
             for (uint32_t col = col0; col < (uint32_t)L::NCOL; col += 32u) {
@@ -1170,7 +1186,7 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint8_t
                 double *dcell = reinterpret_cast<double *>(rows + r * L::STRIDE + L::SHP) + (wide ? col - (uint32_t)L::SHP : 0u);
                 const float v = wide ? (float)*dcell : *cell;
                 if (v != 0.0f) {
-#ifdef RF_EXPERIMENT_STATS
+#ifdef RF_EXPERIMENT_TIMELINE
                     if (g_dbg) atomicAdd(g_dbg + 1, 1ull);
 #endif
                     if (wide) *dcell = 0.0; else *cell = 0.0f;
@@ -1182,9 +1198,6 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint8_t
                     grad_add(dst, v);
                 }
             }
-            if (col0 == 0u) keys[r] = kNone;
-        } else if (col0 == 0u) {
-            touch[r] = (uint8_t)0;
         }
     }
 }
