@@ -319,6 +319,65 @@ def test_large_image_properties(foam_factory):
         assert rel < 1e-4, (k, rel)
 
 
+def _full_size_cases():
+    """BASELINE.json configs at their full size: config 2 (500k points, seed 1) always -- Qhull on 500k
+    points takes about half a minute when the foam is not cached; the 2M-point north-star foam (seed 5)
+    only when its cached triangulation travelled with the repository."""
+    import os
+    from radfoam_amd import foam
+    cases = [pytest.param(500_000, 1, id="config2-500k")]
+    if os.path.exists(os.path.join(foam.default_cache_dir(), "foam_n2000000_s5.npz")):
+        cases.append(pytest.param(2_000_000, 5, id="north-star-2M"))
+    return cases
+
+
+@pytest.mark.parametrize("n_points,seed", _full_size_cases())
+def test_full_size_frame_properties(n_points, seed):
+    """1080x1920 frame, SH degree 2, forward+backward, on the BASELINE foams: properties that do not need the
+    oracle at full size, plus the oracle on a sub-sampled grid of the same rays."""
+    from radfoam_amd import foam
+    d = 2
+    fm = foam.make_synthetic_foam(n_points, d, seed, cache_dir=foam.default_cache_dir())
+    cam, rays, start = H.camera_setup(fm, 1920, 1080)
+    pipe = _pipeline(d)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    r = torch.from_numpy(rays).to(DEV)
+    s = torch.full(r.shape[:-1], int(start), dtype=torch.int64).to(torch.uint32).to(DEV)
+    out = pipe.trace_forward(p, a, adj, off, r, s, return_contribution=True)
+    rgba = out["rgba"]
+    assert torch.isfinite(rgba).all() and float(rgba[..., 3].max()) <= 1.0 and float(rgba.min()) >= 0.0
+    alpha_sum = float(rgba[..., 3].double().sum())
+    assert alpha_sum > 0.2 * 1920 * 1080 * 0.1          # the foam is actually seen
+    assert abs(float(out["contribution"].double().sum()) - alpha_sum) < 1e-3 * alpha_sum
+    assert int(out["num_intersections"].to(torch.int64).max()) <= 1025
+    # every 40th row / column against the oracle, bit for bit
+    sub = np.ascontiguousarray(rays[::40, ::40])
+    ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                          fm["point_adjacency_offsets"], sub, start)
+    np.testing.assert_array_equal(rgba.cpu().numpy()[::40, ::40].view(np.uint32), ref["rgba"].view(np.uint32))
+    np.testing.assert_array_equal(out["num_intersections"].cpu().numpy()[::40, ::40].view(np.uint32),
+                                  ref["num_intersections"])
+    # backward: replaying the trail == walking again, and linear in the incoming gradient
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    g1 = torch.randn(1080, 1920, 4, generator=gen).to(DEV)
+    g2 = torch.randn(1080, 1920, 4, generator=gen).to(DEV)
+    b1 = pipe.trace_backward(p, a, adj, off, r, s, rgba, g1)
+    pg1, ag1 = b1["points_grad"].clone(), b1["attr_grad"].clone()
+    b2 = pipe.trace_backward(p, a, adj, off, r, s, rgba, g2)
+    pg2, ag2 = b2["points_grad"].clone(), b2["attr_grad"].clone()
+    b12 = pipe.trace_backward(p, a, adj, off, r, s, rgba, g1 + g2)
+    for x, y in ((pg1 + pg2, b12["points_grad"]), (ag1 + ag2, b12["attr_grad"])):
+        rel = float((x - y).double().norm() / y.double().norm())
+        assert rel < 1e-4, rel
+    pipe2 = _pipeline(d)
+    pipe2.record_trail = False                            # re-walk, wave-reduced atomics
+    w1 = pipe2.trace_backward(p, a, adj, off, r, s, rgba, g1)
+    for x, y in ((pg1, w1["points_grad"]), (ag1, w1["attr_grad"])):
+        rel = float((x - y).double().norm() / y.double().norm())
+        assert rel < 1e-5, rel
+    assert torch.isfinite(pg1).all() and torch.isfinite(ag1).all() and float(ag1.abs().max()) > 0
+
+
 import glob as _glob
 import os as _os
 
