@@ -9,8 +9,8 @@
 //      cell record, its face list and the colour row are requested together -- one dependent
 //      round trip per hop instead of the reference's four;
 //   3. composites the segment (forward) / accumulates gradients (backward).
-// Forward records the face of every hop (the "trail"); backward replays it instead of scanning
-// again, and sums gradient rows in a block-level LDS write-combining cache before they go to
+// Forward records the cell every hop enters (the "trail"); backward replays it instead of scanning
+// again (it reads no face table at all), and sums gradient rows in a block-level LDS write-combining cache before they go to
 // global atomics.  Tiles are dealt to the XCDs in half-row strips, round-robin, so each XCD's
 // private L2 sees whole strips of the image while all XCDs get the same mix of cheap and
 // expensive image regions.
@@ -22,11 +22,13 @@
 //
 // Kernels (reference counterparts in src/tracing/pipeline.cu):
 //   padded_*_kernel        (no counterpart: prefix sum of the face counts rounded up to 4)
-//   prepare_foam_kernel    prefetch_adjacent_diff_kernel :546-568  (+ cell/face packing)
+//   prepare_foam_kernel    prefetch_adjacent_diff_kernel :546-568  (+ cell/face/link packing)
+//   prepare_geometry_kernel  the same, points-dependent part only (adjacency unchanged)
 //   adjacent_diff_kernel   prefetch_adjacent_diff_kernel :546-568  (plain half4 table)
 //   repack_sh_kernel       (no counterpart: aligned SH rows)
 //   forward_kernel         forward :14-130 and benchmark :472-544
-//   backward_kernel        backward :132-343
+//   backward_kernel        backward :132-343 (re-walk); backward_replay_kernel and
+//                          backward_replay_cached_kernel: the same functor over the recorded trail
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -1101,10 +1103,14 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 // line), at a few 10^9 requests/s chip-wide -- far fewer than the (ray, step) contributions of a
 // frame.  The four waves of a block walk one 16x16 pixel tile, i.e. the same few hundred cells
 // within a few steps of each other, so their contributions are first summed in LDS:
-//   * an open-addressing (kCacheProbes linear probes) table of kCacheRows rows keyed by cell id; a row holds the A
-//     attribute gradients of the cell followed by its 3 point-gradient components;
-//   * lanes add with LDS atomics (ds_add_f32); a lane whose key finds no free row adds straight
-//     to global memory instead;
+//   * an open-addressing (kCacheProbes linear probes) table of kCacheRows rows keyed by cell id;
+//     a row holds the cell's colour gradients (floats), its density gradient and its 3
+//     point-gradient components (doubles);
+//   * colour: lanes of a wave in the same cell are first merged in registers (DPP xor stages), then
+//     each remaining lane adds its 3B values with a float4 read-modify-write under a per-row lock;
+//     density / point gradients: ds_add_f64.  (ds_add_f32 costs 195 clocks per wave instruction on
+//     gfx950 against 9 for ds_add_f64 and 5 for ds_add_u32: scripts/probe/lds_atomics.hip.)
+//     A lane whose key finds no free row adds straight to global memory instead;
 //   * every kEpoch steps the block synchronises and flushes the rows that were not touched during
 //     the epoch (the walk has moved past those cells) with one coalesced row of global atomics,
 //     skipping zeros; rows still in use stay.  At the end everything is flushed.
