@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint8_t
         const uint32_t key = __shfl(my_key, (int)(mine & 63u), 64);
         if (mine < 64u) {
             const uint32_t r = base + mine;
-#ifdef RF_EXPERIMENT_TIMELINE
+#ifdef RF_EXPERIMENT_COUNTERS
             if (col0 == 0u && g_dbg) atomicAdd(g_dbg + 0, 1ull);
 #endif
             for (uint32_t col = col0; col < (uint32_t)L::NCOL; col += 32u) {
@@ -1192,7 +1192,7 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint8_t
                 double *dcell = reinterpret_cast<double *>(rows + r * L::STRIDE + L::SHP) + (wide ? col - (uint32_t)L::SHP : 0u);
                 const float v = wide ? (float)*dcell : *cell;
                 if (v != 0.0f) {
-#ifdef RF_EXPERIMENT_TIMELINE
+#ifdef RF_EXPERIMENT_COUNTERS
                     if (g_dbg) atomicAdd(g_dbg + 1, 1ull);
 #endif
                     if (wide) *dcell = 0.0; else *cell = 0.0f;
@@ -1365,7 +1365,25 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
                     if (act && s_row >= 0 && v[0] == 123.456f) s_rows[s_row * STRIDE] = v[1] + v[5];
 #else
                     bool todo = act && s_row >= 0 && colour;
+#ifdef RF_EXPERIMENT_COUNTERS
+                    // [2] lanes bypassing the table [3] lanes cached [4] lit wave-steps [5] lit lanes
+                    // [6] lit lanes after the pre-merge [7] lock rounds   ([0],[1]: rows / values flushed)
+                    if (p.stats) {
+                        const unsigned long long c2 = __popcll(ballot(act && s_row < 0)), c3 = __popcll(ballot(act && s_row >= 0));
+                        const unsigned long long c5 = __popcll(ballot(G.has && G.row)), c6 = __popcll(ballot(todo));
+                        if (lane == 0) {
+                            atomicAdd(p.stats + 2, c2);
+                            atomicAdd(p.stats + 3, c3);
+                            atomicAdd(p.stats + 4, 1ull);
+                            atomicAdd(p.stats + 5, c5);
+                            atomicAdd(p.stats + 6, c6);
+                        }
+                    }
+#endif
                     while (ballot(todo) != 0ull) {
+#ifdef RF_EXPERIMENT_COUNTERS
+                        if (p.stats && lane == 0) atomicAdd(p.stats + 7, 1ull);
+#endif
                         if (todo) {
                             uint32_t *lock = s_lock + s_row;
                             uint32_t expected = 0u;

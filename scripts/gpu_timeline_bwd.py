@@ -38,9 +38,10 @@ for _ in range(2):
     use[0] = False
 torch.cuda.synchronize()
 head = stats.cpu().numpy()[:8] // 2   # two backward launches were recorded
-print("lit wave-steps %d  lit lanes %d (%.1f/step)  after absorb %d (%.1f/step)  lock rounds %d (%.2f/step)" % (
-    head[4], head[5], head[5] / head[4], head[6], head[6] / head[4], head[7], head[7] / head[4]))
-print("flush: rows %d values (global atomics) %d ; lit lanes: bypass %d cached %d" % tuple(head[:4]))
+if head[4]:   # RF_EXPERIMENT_COUNTERS build
+    print("lit wave-steps %d  lit lanes %d (%.1f/step)  after the pre-merge %d (%.1f/step)  lock rounds %d (%.2f/step)" % (
+        head[4], head[5], head[5] / head[4], head[6], head[6] / head[4], head[7], head[7] / head[4]))
+    print("flush: rows %d values (global atomics) %d ; lit lanes: bypass %d cached %d" % tuple(head[:4]))
 raw = stats.cpu().numpy()[8:].reshape(nblk, 4)
 np.save(os.path.join(ROOT, "gpurun_out", "timeline_bwd.npy"), raw)
 xcc = raw[:, 0] & 0xF
