@@ -1103,69 +1103,89 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 // line), at a few 10^9 requests/s chip-wide -- far fewer than the (ray, step) contributions of a
 // frame.  The four waves of a block walk one 16x16 pixel tile, i.e. the same few hundred cells
 // within a few steps of each other, so their contributions are first summed in LDS:
-//   * an open-addressing (kCacheProbes linear probes) table of kCacheRows rows keyed by cell id;
-//     a row holds the cell's colour gradients (floats), its density gradient and its 3
-//     point-gradient components (doubles);
-//   * colour: lanes of a wave in the same cell are first merged in registers (DPP xor stages), then
-//     each remaining lane adds its 3B values with a float4 read-modify-write under a per-row lock;
-//     density / point gradients: ds_add_f64.  (ds_add_f32 costs 195 clocks per wave instruction on
-//     gfx950 against 9 for ds_add_f64 and 5 for ds_add_u32: scripts/probe/lds_atomics.hip.)
-//     A lane whose key finds no free row adds straight to global memory instead;
-//   * every kEpoch steps the block synchronises and flushes the rows that were not touched during
-//     the epoch (the walk has moved past those cells) with one coalesced row of global atomics,
-//     skipping zeros; rows still in use stay.  At the end everything is flushed.
+//   * an open-addressing (kCacheProbes linear probes) table keyed by cell id; a row holds the cell's
+//     3B colour gradients, its density gradient and its 3 point-gradient components, all as
+//     DOUBLES, and every contribution is one ds_add_f64: no locks, no read-modify-write rounds;
+//     lanes that hit the same address are serialised by the LDS itself (about 11 clocks per
+//     lane).  Measured on gfx950 (scripts/probe/lds_atomics.hip, clocks per wave64 instruction):
+//     ds_add_f64 9, ds_add_u32 5, but ds_add_f32 195 whatever the addresses -- the fp32 LDS atomic
+//     is 20x slower than the fp64 one, which is what rules out rows of floats (the previous
+//     design: float rows, colour updated by float4 read-modify-write under per-row locks, 8 lock
+//     rounds per lit wave-step).  Sums are rounded to fp32 once, at the flush;
+//   * lanes of a wave in the same cell are first merged in registers (DPP xor stages), which cuts
+//     the lanes per address;
+//   * rows of doubles are large (248 B at SH degree 2: 160 rows in the 40 KB a block may use at 4
+//     blocks per CU), so the table is flushed often: every kEpoch steps the block synchronises and
+//     evicts the rows that were not touched during the epoch (the walk has moved past those cells)
+//     with one coalesced row of global atomics each, skipping zeros; rows still in use stay.
+//     A lane whose key finds no free row adds straight to global memory instead (must stay rare:
+//     scattered global atomics are the slow path this cache exists to avoid).
 
-constexpr int kCacheRows = 256;
-constexpr int kCacheBits = 8;
 #ifndef RF_CACHE_PROBES
-#define RF_CACHE_PROBES 4
+#define RF_CACHE_PROBES 8
 #endif
 #ifndef RF_CACHE_EPOCH
-#define RF_CACHE_EPOCH 8
+#define RF_CACHE_EPOCH 4
+#endif
+#ifndef RF_ABSORB_STAGES
+#define RF_ABSORB_STAGES 4
+#endif
+#ifndef RF_CACHE_ROWS_D2
+#define RF_CACHE_ROWS_D2 160
+#endif
+#ifndef RF_BWD_WAVES
+#define RF_BWD_WAVES 4
 #endif
 constexpr int kCacheProbes = RF_CACHE_PROBES;
-constexpr int kEpoch = RF_CACHE_EPOCH;
+constexpr uint32_t kEpoch = RF_CACHE_EPOCH;
 
+// One stage of the in-register pre-reduction that precedes the LDS adds: lanes l and l^BIT that
+// both hold a contribution for the same key are merged into the lower lane; the upper lane drops
+// out (`act` cleared).  Fewer lanes then hit the same LDS address.
+template <int BIT, int NV>
+__device__ __forceinline__ void absorb_stage(uint32_t lane, uint32_t key, bool &act, float (&v)[NV]) {
+    const uint32_t kp = xor_lane_u<BIT>(key);
+    const bool actp = xor_lane_u<BIT>(act ? 1u : 0u) != 0u;
+    const bool same = act && actp && kp == key;
+    if (ballot(same) == 0ull) return;
+    const bool upper = (lane & (uint32_t)BIT) != 0u;
+    const float m = (same && !upper) ? 1.0f : 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = fma_(xor_lane_any<BIT>(v[i]), m, v[i]);
+    if (same && upper) act = false;
+}
+
+template <int NB>
+struct CacheLayout {
+    static constexpr int NCOEF = 3 * NB;
+    static constexpr int COL_DS = NCOEF;
+    static constexpr int COL_PG = NCOEF + 1;
+    static constexpr int NCOL = NCOEF + 4;
+    static constexpr int STRIDE = NCOL | 1;   // odd number of doubles: columns spread over the banks
+    static constexpr int ROWS = NB == 1 ? 256 : (NB == 4 ? 256 : (NB == 9 ? RF_CACHE_ROWS_D2 : 176));
+};
+
+template <int ROWS>
 __device__ __forceinline__ int cache_find(uint32_t *keys, uint32_t key) {
-    const uint32_t h = (key * 2654435761u) >> (32 - kCacheBits);
+    const uint32_t h = (((key * 2654435761u) >> 16) * (uint32_t)ROWS) >> 16;
 #pragma unroll
     for (int probe = 0; probe < kCacheProbes; ++probe) {
-        const uint32_t slot = (h + (uint32_t)probe) & (uint32_t)(kCacheRows - 1);
+        uint32_t slot = h + (uint32_t)probe;
+        slot = slot >= (uint32_t)ROWS ? slot - (uint32_t)ROWS : slot;
         const uint32_t old = atomicCAS(&keys[slot], kNone, key);
         if (old == kNone || old == key) return (int)slot;
     }
     return -1;
 }
 
-// LDS row layout of the block cache: floats [0, 3B) colour gradients, zero padding up to SHP (a
-// multiple of 4); then four DOUBLES: the density gradient and the 3 point-gradient components.
-// The colour part is updated by read-modify-write under a per-row lock (whole float4s); the
-// doubles only ever by ds_add_f64 -- 9 clocks per conflict-free wave instruction on gfx950 where
-// ds_add_f32 takes 195 (scripts/probe/lds_atomics.hip) -- so the two never touch the same bytes.
-// Sums are rounded to fp32 once, at the flush.
 template <int NB>
-struct CacheLayout {
-    static constexpr int NCOEF = 3 * NB;
-    static constexpr int SHP = (NCOEF + 3) & ~3;
-    static constexpr int COL_DS = SHP;
-    static constexpr int COL_PG = SHP + 1;
-    static constexpr int NCOL = SHP + 4;
-    static constexpr int STRIDE = SHP + 8;    // floats: SHP colour slots + 4 doubles; 16-B aligned rows
-};
-
-// Flush rows to global memory (whole block, between barriers).  all == false: only rows whose
-// touch flag is clear; the flags of the others are cleared for the next epoch.  Wave w owns rows
-// [64w, 64w+64): one lane per row decides, then the rows to evict are written out two at a time
-// (one per half-wave, a lane per column: one coalesced row of atomics, zeros skipped).
-template <int NB>
-__device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint8_t *touch, bool all,
-                                            float *attr_grad, float *points_grad,
-                                            unsigned long long *g_dbg = nullptr) {
+__device__ __forceinline__ void cache_flush(double *rows, uint32_t *keys, uint8_t *touch, bool all,
+                                              float *attr_grad, float *points_grad) {
     using L = CacheLayout<NB>;
     constexpr int A = 1 + 3 * NB;
-    static_assert(kCacheRows == kBlock, "one lane per cache row");
     const uint32_t lane = threadIdx.x & 63u, col0 = threadIdx.x & 31u, base = threadIdx.x & ~63u;
-    const uint32_t my_key = keys[threadIdx.x];
+    const bool mine_exists = threadIdx.x < (uint32_t)L::ROWS;
+    const uint32_t my_key = mine_exists ? keys[threadIdx.x] : kNone;
     const bool occupied = my_key != kNone;
     const bool evict = occupied && (all || touch[threadIdx.x] == (uint8_t)0);
     if (occupied && !evict) touch[threadIdx.x] = (uint8_t)0;
@@ -1183,24 +1203,15 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint8_t
         const uint32_t key = __shfl(my_key, (int)(mine & 63u), 64);
         if (mine < 64u) {
             const uint32_t r = base + mine;
-#ifdef RF_EXPERIMENT_COUNTERS
-            if (col0 == 0u && g_dbg) atomicAdd(g_dbg + 0, 1ull);
-#endif
             for (uint32_t col = col0; col < (uint32_t)L::NCOL; col += 32u) {
-                float *cell = rows + r * L::STRIDE + col;
-                const bool wide = col >= (uint32_t)L::SHP;
-                double *dcell = reinterpret_cast<double *>(rows + r * L::STRIDE + L::SHP) + (wide ? col - (uint32_t)L::SHP : 0u);
-                const float v = wide ? (float)*dcell : *cell;
+                double *cell = rows + r * L::STRIDE + col;
+                const float v = (float)*cell;
                 if (v != 0.0f) {
-#ifdef RF_EXPERIMENT_COUNTERS
-                    if (g_dbg) atomicAdd(g_dbg + 1, 1ull);
-#endif
-                    if (wide) *dcell = 0.0; else *cell = 0.0f;
+                    *cell = 0.0;
                     float *dst;
                     if (col < (uint32_t)L::NCOEF) dst = attr_grad + (size_t)key * A + col;
                     else if (col == (uint32_t)L::COL_DS) dst = attr_grad + (size_t)key * A + (A - 1);
-                    else if (col >= (uint32_t)L::COL_PG) dst = points_grad + 3 * (size_t)key + (col - (uint32_t)L::COL_PG);
-                    else continue;   // padding
+                    else dst = points_grad + 3 * (size_t)key + (col - (uint32_t)L::COL_PG);
                     grad_add(dst, v);
                 }
             }
@@ -1208,56 +1219,20 @@ __device__ __forceinline__ void cache_flush(float *rows, uint32_t *keys, uint8_t
     }
 }
 
-// One stage of the in-register pre-reduction that precedes the LDS adds: lanes l and l^BIT that
-// both hold a contribution for the same key are merged into the lower lane; the upper lane drops
-// out (`act` cleared).  Fewer lanes then hit the same LDS address (ds_add_f32 serialises them).
-template <int BIT, int NV>
-__device__ __forceinline__ void absorb_stage(uint32_t lane, uint32_t key, bool &act, float (&v)[NV]) {
-    const uint32_t kp = xor_lane_u<BIT>(key);
-    const bool actp = xor_lane_u<BIT>(act ? 1u : 0u) != 0u;
-    const bool same = act && actp && kp == key;
-    if (ballot(same) == 0ull) return;
-    const bool upper = (lane & (uint32_t)BIT) != 0u;
-    const float m = (same && !upper) ? 1.0f : 0.0f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = fma_(xor_lane_any<BIT>(v[i]), m, v[i]);
-    if (same && upper) act = false;
-}
-
-#ifndef RF_ABSORB_STAGES
-#define RF_ABSORB_STAGES 4
-#endif
-template <int NV>
-__device__ __forceinline__ void absorb_all(uint32_t lane, uint32_t key, bool &act, float (&v)[NV]) {
-    if constexpr (RF_ABSORB_STAGES > 0) absorb_stage<1, NV>(lane, key, act, v);
-    if constexpr (RF_ABSORB_STAGES > 1) absorb_stage<2, NV>(lane, key, act, v);
-    if constexpr (RF_ABSORB_STAGES > 2) absorb_stage<4, NV>(lane, key, act, v);
-    if constexpr (RF_ABSORB_STAGES > 3) absorb_stage<8, NV>(lane, key, act, v);
-    if constexpr (RF_ABSORB_STAGES > 4) absorb_stage<16, NV>(lane, key, act, v);
-    if constexpr (RF_ABSORB_STAGES > 5) absorb_stage<32, NV>(lane, key, act, v);
-}
-
 template <int DEG, bool HALF, bool QUANT>
-#ifndef RF_BWD_WAVES
-#define RF_BWD_WAVES 4
-#endif
 __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backward_replay_cached_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
     constexpr int A = 1 + 3 * NB;
     using L = CacheLayout<NB>;
     constexpr int STRIDE = L::STRIDE;
-    __shared__ __attribute__((aligned(16))) float s_rows[kCacheRows * STRIDE];
-    __shared__ uint32_t s_keys[kCacheRows];
-    __shared__ uint32_t s_lock[kCacheRows];
-    __shared__ uint8_t s_touch[kCacheRows];
-#ifdef RF_EXPERIMENT_TIMELINE
-    const unsigned long long tl_start = wall_clock64();
-#endif
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(kCacheRows * STRIDE); i += kBlock) s_rows[i] = 0.0f;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kCacheRows; i += kBlock) {
+    constexpr int ROWS = L::ROWS;
+    __shared__ __attribute__((aligned(16))) double s_rows[ROWS * STRIDE];
+    __shared__ uint32_t s_keys[ROWS];
+    __shared__ uint8_t s_touch[ROWS];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(ROWS * STRIDE); i += kBlock) s_rows[i] = 0.0;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)ROWS; i += kBlock) {
         s_keys[i] = kNone;
         s_touch[i] = (uint8_t)0;
-        s_lock[i] = 0u;
     }
     __syncthreads();
 
@@ -1273,7 +1248,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
     uint32_t hops = 0;
     if (alive) {
         hops = p.trail_hops[slot];
-        if (hops > cap) alive = false;   // did not fit in the trail: left to the re-walk launch
+        if (hops > cap) alive = false;
     }
     if (alive) load_backward_ray<DEG, HALF>(p, ray, R, cur);
     float sh[NB];
@@ -1331,13 +1306,11 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
             id1 = id2;
             q0 = q1;
 
-            // add this hop's gradients to the block cache (or straight to memory on a table conflict)
-            {
-                const uint32_t lane = threadIdx.x & 63u;
-                // -- density gradient (every composited segment) and colour row (lit cells only)
+            const uint32_t lane = threadIdx.x & 63u;
+            if (ballot(G.has) != 0ull) {
                 bool act = G.has;
-                float dsv[1] = {G.dL_ds};
                 if (ballot(G.has && G.row) != 0ull) {
+                    // lit wave-step: colour + density of every lane with a contribution
                     float v[A];
 #pragma unroll
                     for (int k = 0; k < 3 * NB; ++k) {
@@ -1345,99 +1318,51 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
                         v[k] = G.row ? sh[k / 3] * gc : 0.0f;
                     }
                     v[A - 1] = G.dL_ds;
-                    absorb_all<A>(lane, G.cur, act, v);
-                    // rows whose colour part is not all zero need the locked read-modify-write
-                    bool colour = false;
+                    if constexpr (RF_ABSORB_STAGES > 0) absorb_stage<1, A>(lane, G.cur, act, v);
+                    if constexpr (RF_ABSORB_STAGES > 1) absorb_stage<2, A>(lane, G.cur, act, v);
+                    if constexpr (RF_ABSORB_STAGES > 2) absorb_stage<4, A>(lane, G.cur, act, v);
+                    if constexpr (RF_ABSORB_STAGES > 3) absorb_stage<8, A>(lane, G.cur, act, v);
+                    const int s_row = act ? cache_find<ROWS>(s_keys, G.cur) : -1;
+                    if (act && s_row >= 0) {
+                        s_touch[s_row] = (uint8_t)1;
+                        double *row = s_rows + s_row * STRIDE;
+                        atomicAdd(row + L::COL_DS, (double)v[A - 1]);
+                        bool colour = false;
 #pragma unroll
-                    for (int k = 0; k < 3 * NB; ++k) colour = colour || (v[k] != 0.0f);
-                    const int s_row = act ? cache_find(s_keys, G.cur) : -1;
-                    if (act && s_row < 0) {
+                        for (int k = 0; k < 3 * NB; ++k) colour = colour || (v[k] != 0.0f);
+                        if (colour) {
+#pragma unroll
+                            for (int k = 0; k < 3 * NB; ++k) atomicAdd(row + k, (double)v[k]);
+                        }
+                    } else if (act) {
                         float *dst = p.attr_grad + (size_t)G.cur * A;
 #pragma unroll
                         for (int k = 0; k < A; ++k)
                             if (v[k] != 0.0f) grad_add(dst + k, v[k]);
                     }
+                } else {
+                    const int s_row = act ? cache_find<ROWS>(s_keys, G.cur) : -1;
                     if (act && s_row >= 0) {
                         s_touch[s_row] = (uint8_t)1;
-                        atomicAdd(reinterpret_cast<double *>(s_rows + s_row * STRIDE + L::SHP), (double)v[A - 1]);
-                    }
-#ifdef RF_X_NO_LITADD
-                    if (act && s_row >= 0 && v[0] == 123.456f) s_rows[s_row * STRIDE] = v[1] + v[5];
-#else
-                    bool todo = act && s_row >= 0 && colour;
-#ifdef RF_EXPERIMENT_COUNTERS
-                    // [2] lanes bypassing the table [3] lanes cached [4] lit wave-steps [5] lit lanes
-                    // [6] lit lanes after the pre-merge [7] lock rounds   ([0],[1]: rows / values flushed)
-                    if (p.stats) {
-                        const unsigned long long c2 = __popcll(ballot(act && s_row < 0)), c3 = __popcll(ballot(act && s_row >= 0));
-                        const unsigned long long c5 = __popcll(ballot(G.has && G.row)), c6 = __popcll(ballot(todo));
-                        if (lane == 0) {
-                            atomicAdd(p.stats + 2, c2);
-                            atomicAdd(p.stats + 3, c3);
-                            atomicAdd(p.stats + 4, 1ull);
-                            atomicAdd(p.stats + 5, c5);
-                            atomicAdd(p.stats + 6, c6);
-                        }
-                    }
-#endif
-                    while (ballot(todo) != 0ull) {
-#ifdef RF_EXPERIMENT_COUNTERS
-                        if (p.stats && lane == 0) atomicAdd(p.stats + 7, 1ull);
-#endif
-                        if (todo) {
-                            uint32_t *lock = s_lock + s_row;
-                            uint32_t expected = 0u;
-                            if (__hip_atomic_compare_exchange_strong(lock, &expected, 1u, __ATOMIC_ACQUIRE,
-                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                                float4 *r4 = reinterpret_cast<float4 *>(s_rows + s_row * STRIDE);
-#pragma unroll
-                                for (int j = 0; j < L::SHP / 4; ++j) {
-                                    float4 x = r4[j];
-                                    x.x += (4 * j + 0 < 3 * NB) ? v[(4 * j + 0) % A] : 0.0f;
-                                    x.y += (4 * j + 1 < 3 * NB) ? v[(4 * j + 1) % A] : 0.0f;
-                                    x.z += (4 * j + 2 < 3 * NB) ? v[(4 * j + 2) % A] : 0.0f;
-                                    x.w += (4 * j + 3 < 3 * NB) ? v[(4 * j + 3) % A] : 0.0f;
-                                    r4[j] = x;
-                                }
-                                __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                todo = false;
-                            }
-                        }
-                    }
-#endif
-                } else if (ballot(G.has) != 0ull) {
-                    if (act) {
-                        const int s_row = cache_find(s_keys, G.cur);
-                        if (s_row >= 0) {
-                            s_touch[s_row] = (uint8_t)1;
-#ifdef RF_X_NO_DENSADD
-                            if (dsv[0] == 123.456f) s_rows[s_row * STRIDE] = dsv[0];
-#else
-                            atomicAdd(reinterpret_cast<double *>(s_rows + s_row * STRIDE + L::SHP), (double)dsv[0]);
-#endif
-                        } else {
-                            grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), dsv[0]);
-                        }
+                        atomicAdd(s_rows + s_row * STRIDE + L::COL_DS, (double)G.dL_ds);
+                    } else if (act) {
+                        grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), G.dL_ds);
                     }
                 }
-                // -- point gradient of the previous cell
-                if (ballot(G.has && G.pg_on) != 0ull) {
-                    bool pact = G.has && G.pg_on;
-                    float pv[3] = {G.px, G.py, G.pz};
-                    if (pact) {
-                        const int s_pg = cache_find(s_keys, G.prev);
-                        if (s_pg >= 0) {
-                            s_touch[s_pg] = (uint8_t)1;
-                            double *dst = reinterpret_cast<double *>(s_rows + s_pg * STRIDE + L::SHP) + 1;
-                            atomicAdd(dst + 0, (double)pv[0]);
-                            atomicAdd(dst + 1, (double)pv[1]);
-                            atomicAdd(dst + 2, (double)pv[2]);
-                        } else {
-                            float *dst = p.points_grad + 3 * (size_t)G.prev;
-                            grad_add(dst + 0, pv[0]);
-                            grad_add(dst + 1, pv[1]);
-                            grad_add(dst + 2, pv[2]);
-                        }
+                const bool pact = G.has && G.pg_on;
+                if (ballot(pact) != 0ull) {
+                    const int s_pg = pact ? cache_find<ROWS>(s_keys, G.prev) : -1;
+                    if (pact && s_pg >= 0) {
+                        s_touch[s_pg] = (uint8_t)1;
+                        double *dst = s_rows + s_pg * STRIDE + L::COL_PG;
+                        atomicAdd(dst + 0, (double)G.px);
+                        atomicAdd(dst + 1, (double)G.py);
+                        atomicAdd(dst + 2, (double)G.pz);
+                    } else if (pact) {
+                        float *dst = p.points_grad + 3 * (size_t)G.prev;
+                        grad_add(dst + 0, G.px);
+                        grad_add(dst + 1, G.py);
+                        grad_add(dst + 2, G.pz);
                     }
                 }
             }
@@ -1446,22 +1371,12 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
             G.pg_on = false;
         }
         it++;
-        if ((it & (uint32_t)(kEpoch - 1)) == 0u) {
+        if ((it & (kEpoch - 1u)) == 0u) {
             block_alive = __syncthreads_or(alive ? 1 : 0) != 0;
-            cache_flush<NB>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad, p.stats);
+            cache_flush<NB>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad);
             __syncthreads();
         }
     }
-#ifdef RF_EXPERIMENT_TIMELINE
-    if (p.stats && threadIdx.x == 0) {
-        unsigned long long *rec = p.stats + 8 + 4ull * blockIdx.x;
-        rec[0] = (unsigned long long)__builtin_amdgcn_s_getreg(6164) |
-                 ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 8);
-        rec[1] = tl_start;
-        rec[2] = wall_clock64();
-        rec[3] = it;
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
