@@ -66,8 +66,9 @@ typedef struct rf_launch_opts {
     uint32_t image_width;     /* rays form a row-major [image_height, image_width] grid: lets a wave  */
     uint32_t image_height;    /*   own an 8x8 pixel tile.  0,0 = treat rays as a flat list            */
     uint32_t backward_mode;   /* rf_trace_backward only: 0 = auto, 1 = per-lane atomics, 2 = wave     */
-                              /*   pre-reduced atomics, 3 = block-level LDS write-combining (needs    */
-                              /*   the trail; falls back to 2 without it)                             */
+                              /*   pre-reduced atomics, 3 = block-level LDS write-combining, 4 =      */
+                              /*   direct row-coalesced atomics (3, 4 need the trail and fall back to */
+                              /*   2 without it; auto = 3 for image-shaped batches, 4 for flat ones)  */
     uint64_t *stats;          /* optional device uint64[8]: walk counters for the roofline figure     */
                               /*   [0] cells scanned [1] faces scanned [2] hops [3] segments          */
                               /*   [4] lit segments; accumulated with atomics, caller zeroes          */
@@ -79,6 +80,12 @@ typedef struct rf_launch_opts {
     uint32_t *trail_hops;     /* device uint32[trail_slots]                                           */
     uint32_t trail_cap;
     uint32_t trail_slots;     /* >= rf_trail_slots(num_rays, image_width, image_height)               */
+    /* Flat ray lists only (image_width = 0), optional: device uint32[num_rays], a permutation of the  */
+    /* ray indices (rf_build_ray_order).  Thread slot s traces ray ray_order[s], so that the rays of a */
+    /* wave / block are neighbours in space even when the caller's batch is shuffled (train.py:61);    */
+    /* every input and output stays indexed by the caller's ray index.  The same order must be given   */
+    /* to the rf_trace_backward call that replays a trail.                                             */
+    const uint32_t *ray_order;
 } rf_launch_opts;
 
 /* Last error message of the calling thread ("" if none). */
@@ -203,6 +210,15 @@ int rf_nearest_point(const float *points, uint32_t num_points, const float *quer
 int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_t *point_adjacency,
                          const uint32_t *point_adjacency_offsets, uint32_t *indices,
                          float *cell_radius, void *stream);
+
+/* Coherent processing order for a flat batch of rays: sorts the ray indices by (entry cell, Morton
+ * code of the direction on a 2^16 x 2^16 octahedral grid), so that 64 / 256 consecutive entries are
+ * a compact patch of directions from one origin.  rays is float[num_rays][6] (direction need not be
+ * normalised), start_point_index uint32[num_rays]; writes the permutation to ray_order.
+ * No counterpart in the reference, whose kernels take the batch as it comes. */
+size_t rf_ray_order_workspace_bytes(uint32_t num_rays);
+int rf_build_ray_order(const float *rays, const uint32_t *start_point_index, uint32_t num_rays,
+                       uint32_t *ray_order, void *workspace, size_t workspace_bytes, void *stream);
 
 /* CSR point adjacency from tetrahedra (find_adjacency, src/delaunay/delaunay.cu:140-229): tets is
  * uint32[num_tets][4]; writes point_adjacency_offsets[num_points + 1], the neighbours of every

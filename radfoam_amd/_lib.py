@@ -54,6 +54,7 @@ class LaunchOpts(C.Structure):
         ("trail_hops", C.c_void_p),
         ("trail_cap", C.c_uint32),
         ("trail_slots", C.c_uint32),
+        ("ray_order", C.c_void_p),
     ]
 
 
@@ -78,6 +79,8 @@ SYMBOLS = {
     "rf_pack_attributes_backward": (_INT, [_INT, _U32, _P, C.c_float, _P, _P, _P, _P, _P]),
     "rf_nearest_point": (_INT, [_P, _U32, _P, _U32, _P, _P, _P]),
     "rf_farthest_neighbor": (_INT, [_P, _U32, _P, _P, _P, _P, _P]),
+    "rf_ray_order_workspace_bytes": (C.c_size_t, [_U32]),
+    "rf_build_ray_order": (_INT, [_P, _P, _U32, _P, _P, C.c_size_t, _P]),
     "rf_adjacency_workspace_bytes": (C.c_size_t, [_U32]),
     "rf_build_adjacency": (_INT, [_P, _U32, _U32, _P, _P, _P, _P, C.c_size_t, _P]),
     "rf_trace_benchmark": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _P,

@@ -59,6 +59,7 @@ struct FoamView {
 struct RayGrid {
     uint32_t num_rays;
     uint32_t img_w, img_h;  // 0,0: flat list
+    const uint32_t *order;  // flat list only, optional: thread slot s traces ray order[s] (rf_build_ray_order)
 };
 
 struct FwdParams {
@@ -174,8 +175,9 @@ __device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray, uint32_
         ray = y * g.img_w + x;
         return x < g.img_w && y < g.img_h;
     }
-    ray = slot;
-    return ray < g.num_rays;
+    if (slot >= g.num_rays) return false;
+    ray = g.order ? g.order[slot] : slot;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1380,6 +1382,173 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
 }
 
 // ------------------------------------------------------------------------------------------
+// MODE 4: trail replay with direct, row-coalesced global atomics -- for flat (training-like) batches.
+//
+// A sparse batch leaves little to combine: even in the coherent order of rf_build_ray_order the 64
+// rays of a wave sit in 40-50 different cells, a cell is visited by two or three rays of the whole
+// batch, and the block cache turns into a queue of rows that are written once and flushed (or do
+// not fit: measured 26 ms for 1M rays on the 2M-point foam against 4.2 ms for a dense 2M-ray frame).
+// What the memory side is good at (scripts/probe/global_atomics.hip): 21 G scattered fp32 atomics
+// per second when every request is its own cache line, 3.4 G when successive instructions hit the
+// same lines (a lane walking along its row).  So here every contribution goes straight to memory,
+// shaped for the atomic unit: the density gradient as one scattered atomic per lane, a colour row
+// as ONE instruction whose lanes are the row's columns -- the lanes' rows are transposed through a
+// small LDS staging area of the wave (written lane-major, read column-major, two rows per pass).
+// No table, no epochs, no block barriers.
+template <int DEG, bool HALF, bool QUANT>
+__global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : 3)) void backward_replay_direct_kernel(BwdParams p) {
+    constexpr int NB = sh_dim(DEG);
+    constexpr int A = 1 + 3 * NB;
+    constexpr int NC = 3 * NB;
+    constexpr int SHP = (NC + 3) & ~3;             // staged floats per lane, float4-padded
+    constexpr int PITCH = SHP + 4;                 // + one float4: rows rotate through the banks
+    __shared__ __attribute__((aligned(16))) float s_stage[kBlock * PITCH];
+    const uint32_t lane = threadIdx.x & 63u;
+    float *stage = s_stage + (threadIdx.x & ~63u) * PITCH;   // this wave's 64 slots
+
+    uint32_t ray, slot;
+    bool alive = map_ray(p.grid, ray, slot);
+    const FoamView &fv = p.foam;
+    const size_t slots = p.trail_slots;
+    const uint32_t cap = p.trail_cap;
+
+    BwdRay R;
+    init_backward_ray(R);
+    uint32_t cur = 0;
+    uint32_t hops = 0;
+    if (alive) {
+        hops = p.trail_hops[slot];
+        if (hops > cap) alive = false;   // did not fit in the trail: left to the re-walk launch
+    }
+    if (alive) load_backward_ray<DEG, HALF>(p, ray, R, cur);
+    float sh[NB];
+    sh_basis<DEG>(R.dx, R.dy, R.dz, sh);
+    const uint32_t max_steps = p.settings.max_intersections;
+    const uint32_t recorded = hops < cap ? hops : cap;
+
+    float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t id0 = 0, id1 = 0;
+    if (alive) {
+        head = fv.cells[cur];
+        if (recorded > 0) id0 = p.trail[slot];
+        if (recorded > 1) id1 = p.trail[slots + slot];
+        if (recorded > 0) q0 = fv.cells[id0];
+    }
+
+    StepGrad G;
+    clear_step(G);
+    uint32_t i = 0;
+    uint32_t n = 0;
+    while (ballot(alive) != 0ull) {
+        if (alive) {
+            n++;
+            if (n > max_steps) alive = false;
+        }
+        if (alive && i >= hops) alive = false;
+        float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t id2 = 0;
+        if (alive) {
+            if (i + 1 < recorded) q1 = fv.cells[id1];
+            if (i + 2 < recorded) id2 = p.trail[(size_t)(i + 2) * slots + slot];
+        }
+        float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float t1 = 0.0f;
+        if (alive) {
+            nhead = q0;
+            float ox, oy, oz, dp;
+            face_offset(head, nhead, ox, oy, oz);
+            face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
+        }
+        if (alive) {
+            if (t1 > R.t0) {
+                if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
+            }
+            R.t0 = __builtin_fmaxf(R.t0, t1);
+            cur = id0;
+            head = nhead;
+            i++;
+        }
+        id0 = id1;
+        id1 = id2;
+        q0 = q1;
+
+        if (ballot(G.has) != 0ull) {
+            // density gradient: lanes of the wave in the same cell merged (DPP xor stages), then one
+            // scattered atomic per remaining lane -- these single-float atomics are the bulk of the
+            // requests (every segment has one): 17.7 ms without the merge, 13.2 ms with it
+            {
+                bool dact = G.has;
+                float dv[1] = {G.dL_ds};
+                absorb_stage<1, 1>(lane, G.cur, dact, dv);
+                absorb_stage<2, 1>(lane, G.cur, dact, dv);
+                absorb_stage<4, 1>(lane, G.cur, dact, dv);
+                absorb_stage<8, 1>(lane, G.cur, dact, dv);
+                if (dact && dv[0] != 0.0f) grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), dv[0]);
+            }
+            // point gradient of the previous cell
+            if (ballot(G.has && G.pg_on) != 0ull) {
+                bool pact = G.has && G.pg_on;
+                float pv[3] = {G.px, G.py, G.pz};
+                absorb_stage<1, 3>(lane, G.prev, pact, pv);
+                absorb_stage<2, 3>(lane, G.prev, pact, pv);
+                absorb_stage<4, 3>(lane, G.prev, pact, pv);
+                absorb_stage<8, 3>(lane, G.prev, pact, pv);
+                if (pact) {
+                    float *dst = p.points_grad + 3 * (size_t)G.prev;
+                    if (pv[0] != 0.0f) grad_add(dst + 0, pv[0]);
+                    if (pv[1] != 0.0f) grad_add(dst + 1, pv[1]);
+                    if (pv[2] != 0.0f) grad_add(dst + 2, pv[2]);
+                }
+            }
+            // colour rows: stage lane-major, emit column-major (two rows per pass, a lane per column)
+            const bool lit = G.has && G.row;
+            unsigned long long todo = ballot(lit);
+            if (todo != 0ull) {
+                if (lit) {
+                    float4 *dst4 = reinterpret_cast<float4 *>(stage + lane * PITCH);
+#pragma unroll
+                    for (int j = 0; j < SHP / 4; ++j) {
+                        float x[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int k = 4 * j + c;
+                            const float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
+                            x[c] = k < NC ? sh[(k < NC ? k : 0) / 3] * gc : 0.0f;
+                        }
+                        dst4[j] = make_float4(x[0], x[1], x[2], x[3]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t col0 = lane & 31u;
+                while (todo != 0ull) {
+                    const uint32_t b0 = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    uint32_t b1 = 64u;
+                    if (todo != 0ull) {
+                        b1 = (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                    }
+                    const uint32_t mine = lane < 32u ? b0 : b1;
+                    const uint32_t cell = __shfl(G.cur, (int)(mine & 63u), 64);
+                    if (mine < 64u) {
+                        for (uint32_t col = col0; col < (uint32_t)NC; col += 32u) {
+                            const float v = stage[mine * PITCH + col];
+                            if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * A + col, v);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();   // the slots are rewritten next step
+            }
+        }
+        G.has = false;
+        G.row = false;
+        G.pg_on = false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // foam packing
 
 __device__ __forceinline__ uint2 pack_diff(float dx, float dy, float dz) {
@@ -1716,7 +1885,12 @@ struct LaunchBackward {
                 hipLaunchKernelGGL((backward_replay_kernel<DEG, HALF, 1>), dim3(nb), dim3(kBlock), 0, stream, p);
             else if (mode == 2)
                 hipLaunchKernelGGL((backward_replay_kernel<DEG, HALF, 2>), dim3(nb), dim3(kBlock), 0, stream, p);
-            else if (p.nq)
+            else if (mode == 4) {
+                if (p.nq)
+                    hipLaunchKernelGGL((backward_replay_direct_kernel<DEG, HALF, true>), dim3(nb), dim3(kBlock), 0, stream, p);
+                else
+                    hipLaunchKernelGGL((backward_replay_direct_kernel<DEG, HALF, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+            } else if (p.nq)
                 hipLaunchKernelGGL((backward_replay_cached_kernel<DEG, HALF, true>), dim3(nb), dim3(kBlock), 0, stream, p);
             else
                 hipLaunchKernelGGL((backward_replay_cached_kernel<DEG, HALF, false>), dim3(nb), dim3(kBlock), 0, stream, p);
@@ -1736,11 +1910,13 @@ struct LaunchBackward {
 };
 
 static RayGrid make_grid(uint32_t num_rays, const rf_launch_opts *opts) {
-    RayGrid g{num_rays, 0u, 0u};
+    RayGrid g{num_rays, 0u, 0u, nullptr};
     if (opts && opts->image_width && opts->image_height &&
         (uint64_t)opts->image_width * opts->image_height == num_rays) {
         g.img_w = opts->image_width;
         g.img_h = opts->image_height;
+    } else if (opts) {
+        g.order = opts->ray_order;
     }
     return g;
 }
@@ -1885,8 +2061,8 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_point_indices || !depth_grad))
         return fail(RF_ERR_INVALID_ARGUMENT, "depth_grad must be provided if depth_quantiles is provided");
-    if (opts->backward_mode > 3u)
-        return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0..3");
+    if (opts->backward_mode > 4u)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0..4");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -1923,10 +2099,11 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
         p.trail_cap = opts->trail_cap;
         p.trail_slots = opts->trail_slots;
     }
-    // 0 = auto: block-cached scatter when a trail is replayed, wave-reduced scatter otherwise
+    // 0 = auto: with a trail to replay, the block cache for image-shaped batches (dense: many rays per
+    // cell and tile) and direct row atomics for flat ones; wave-reduced scatter without a trail
     int mode = (int)opts->backward_mode;
-    if (mode == 0) mode = p.trail ? 3 : 2;
-    if (mode == 3 && !p.trail) mode = 2;
+    if (mode == 0) mode = p.trail ? (p.grid.img_w ? 3 : 4) : 2;
+    if ((mode == 3 || mode == 4) && !p.trail) mode = 2;
     return dispatch<LaunchBackward>(sh_degree, half, p, mode, s);
 }
 
@@ -1960,7 +2137,7 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
     }
     FwdParams p{};
     p.foam = make_view(L, opts->workspace, attributes, point_adjacency_offsets);
-    p.grid = RayGrid{camera->width * camera->height, camera->width, camera->height};
+    p.grid = RayGrid{camera->width * camera->height, camera->width, camera->height, nullptr};
     p.settings = *settings;
     p.start = start_point_index;
     p.cam = *camera;

@@ -131,7 +131,8 @@ class Pipeline:
         self._cache = _FoamCache()
         #: reuse the packed foam between calls while the inputs are unchanged
         self.cache_foam = True
-        #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics (rf_launch_opts.backward_mode)
+        #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics, 3 block cache, 4 direct row atomics
+        #: (rf_launch_opts.backward_mode)
         self.backward_mode = 0
         #: trace_forward records the face every hop went through so that a trace_backward call on
         #: the same inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).
@@ -140,6 +141,13 @@ class Pipeline:
         #: hops recorded per ray; rays that take more are re-scanned past this point
         self.trail_steps = 256
         self._trail = None
+        #: flat ray batches (anything but [H, W, 6] images) are traced in a coherent order -- sorted by
+        #: entry cell and direction (rf_build_ray_order) -- so that shuffled training batches
+        #: (train.py:61) keep the locality the kernels rely on; results do not depend on it
+        self.reorder_rays = True
+        #: batches smaller than this are traced as they come
+        self.reorder_min_rays = 16384
+        self._order = None
 
     # -- introspection (Pipeline::attribute_dim / attribute_type, pipeline.cu:768-774) ----------
     def attribute_dim(self) -> int:
@@ -272,6 +280,25 @@ class Pipeline:
         return (tuple(self._tkey(t) for t in foam), self._tkey(rays), self._tkey(start), self._tkey(quantiles),
                 float(settings.weight_threshold), int(settings.max_intersections))
 
+    def _ray_order(self, opts, rays_c, start_c, num_rays):
+        """Set opts.ray_order for a flat batch: the permutation rf_build_ray_order computes, cached on
+        the identity + version of (rays, start_point) so that trace_backward reuses trace_forward's."""
+        if not self.reorder_rays or opts.image_width or num_rays < self.reorder_min_rays:
+            return
+        key = (self._tkey(rays_c), self._tkey(start_c))
+        cached = self._order
+        if cached is None or cached["key"] != key:
+            dev = rays_c.device
+            order = torch.empty(num_rays, dtype=torch.int32, device=dev)
+            nbytes = int(self._lib.rf_ray_order_workspace_bytes(num_rays))
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = self._lib.rf_build_ray_order(_ptr(rays_c), _ptr(start_c), num_rays, _ptr(order), _ptr(ws),
+                                                  ws.numel(), _stream_ptr(dev))
+            _lib.check(rc)
+            cached = self._order = {"key": key, "order": order, "refs": (rays_c, start_c)}
+        opts.ray_order = cached["order"].data_ptr()
+
     def _new_trail(self, opts, num_rays, dev):
         slots = int(self._lib.rf_trail_slots(num_rays, opts.image_width, opts.image_height))
         cap = max(1, int(self.trail_steps))
@@ -329,6 +356,7 @@ class Pipeline:
             depth_indices = torch.zeros(batch + (nq,), dtype=torch.uint32, device=dev)
 
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
+        self._ray_order(opts, rays_c, start_c, num_rays)
         trail = None
         if self.record_trail and num_rays > 0:
             trail = self._new_trail(opts, num_rays, dev)
@@ -346,6 +374,7 @@ class Pipeline:
                 "key": self._trail_key(foam, rays_c, start_c, quantiles_c, settings),
                 "refs": foam + (rays_c, start_c, quantiles_c),   # keep the storages from being recycled
                 "trail": trail[0], "hops": trail[1], "cap": opts.trail_cap, "slots": opts.trail_slots,
+                "order": opts.ray_order,   # the slot -> ray mapping the trail was recorded under
             }
         else:
             self._trail = None
@@ -447,9 +476,11 @@ class Pipeline:
         ray_grad = torch.zeros_like(rays_c)
 
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
+        self._ray_order(opts, rays_c, start_c, num_rays)
         tr = self._trail
-        if tr is not None and tr["key"] == self._trail_key((points_c, attributes_c, adjacency_c, offsets_c),
-                                                            rays_c, start_c, quantiles_c, settings):
+        if tr is not None and tr["order"] == opts.ray_order and \
+                tr["key"] == self._trail_key((points_c, attributes_c, adjacency_c, offsets_c),
+                                             rays_c, start_c, quantiles_c, settings):
             opts.trail = tr["trail"].data_ptr()
             opts.trail_hops = tr["hops"].data_ptr()
             opts.trail_cap = tr["cap"]
