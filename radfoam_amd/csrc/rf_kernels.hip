@@ -27,8 +27,10 @@
 //   adjacent_diff_kernel   prefetch_adjacent_diff_kernel :546-568  (plain half4 table)
 //   repack_sh_kernel       (no counterpart: aligned SH rows)
 //   forward_kernel         forward :14-130 and benchmark :472-544
-//   backward_kernel        backward :132-343 (re-walk); backward_replay_kernel and
-//                          backward_replay_cached_kernel: the same functor over the recorded trail
+//   backward_kernel        backward :132-343 (re-walk); backward_replay_kernel (modes 1, 2),
+//                          backward_replay_cached_kernel (mode 3, image-shaped batches) and
+//                          backward_replay_direct_kernel (mode 4, flat batches): the same functor over
+//                          the recorded trail
 #include <hip/hip_runtime.h>
 
 #include <cmath>
