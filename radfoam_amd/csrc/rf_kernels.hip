@@ -1140,6 +1140,12 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 #ifndef RF_BWD_WAVES
 #define RF_BWD_WAVES 4
 #endif
+#ifndef RF_DTABLE_ROWS
+#define RF_DTABLE_ROWS 768
+#endif
+#ifndef RF_DTABLE_EPOCH
+#define RF_DTABLE_EPOCH 4
+#endif
 constexpr int kCacheProbes = RF_CACHE_PROBES;
 constexpr uint32_t kEpoch = RF_CACHE_EPOCH;
 
@@ -1393,20 +1399,37 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
 // What the memory side is good at (scripts/probe/global_atomics.hip): 21 G scattered fp32 atomics
 // per second when every request is its own cache line, 3.4 G when successive instructions hit the
 // same lines (a lane walking along its row).  So here every contribution goes straight to memory,
-// shaped for the atomic unit: the density gradient as one scattered atomic per lane, a colour row
-// as ONE instruction whose lanes are the row's columns -- the lanes' rows are transposed through a
-// small LDS staging area of the wave (written lane-major, read column-major, two rows per pass).
-// No table, no epochs, no block barriers.
+// shaped for the atomic unit: a colour row as ONE instruction whose lanes are the row's columns -- the
+// lanes' rows are transposed through a small LDS staging area of the wave (written lane-major, read
+// column-major, two rows per pass); the point gradient as three scattered atomics per lane.  Only the
+// density gradient -- one value per segment, 10 of the 13 ms when sent directly -- still goes through
+// a block-level table: 768 cells x one double, same-cell lanes pre-merged by DPP, entries untouched
+// for 4 steps flushed as single atomics (13.1 -> 8.1 ms).
 template <int DEG, bool HALF, bool QUANT>
 __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : 3)) void backward_replay_direct_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
     constexpr int A = 1 + 3 * NB;
     constexpr int NC = 3 * NB;
     constexpr int SHP = (NC + 3) & ~3;             // staged floats per lane, float4-padded
-    constexpr int PITCH = SHP + 4;                 // + one float4: rows rotate through the banks
+    constexpr int PITCH = SHP;
     __shared__ __attribute__((aligned(16))) float s_stage[kBlock * PITCH];
     const uint32_t lane = threadIdx.x & 63u;
     float *stage = s_stage + (threadIdx.x & ~63u) * PITCH;   // this wave's 64 slots
+    // density gradients (one per segment: the bulk of the requests) are first summed per cell in a
+    // small block-level table of doubles; entries untouched for an epoch go out as single atomics
+    constexpr int DROWS = RF_DTABLE_ROWS;
+    constexpr uint32_t kDEpoch = RF_DTABLE_EPOCH;
+    __shared__ double s_dens[DROWS];
+    __shared__ uint32_t s_dkeys[DROWS];
+    __shared__ uint8_t s_dtouch[DROWS];
+    for (uint32_t e = threadIdx.x; e < (uint32_t)DROWS; e += kBlock) {
+        s_dens[e] = 0.0;
+        s_dkeys[e] = kNone;
+        s_dtouch[e] = (uint8_t)0;
+    }
+    __syncthreads();
+    uint32_t it = 0;
+    bool block_alive = true;
 
     uint32_t ray, slot;
     bool alive = map_ray(p.grid, ray, slot);
@@ -1442,7 +1465,8 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : 3)) void backward_replay_di
     clear_step(G);
     uint32_t i = 0;
     uint32_t n = 0;
-    while (ballot(alive) != 0ull) {
+    while (block_alive) {
+      if (ballot(alive) != 0ull) {
         if (alive) {
             n++;
             if (n > max_steps) alive = false;
@@ -1486,7 +1510,13 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : 3)) void backward_replay_di
                 absorb_stage<2, 1>(lane, G.cur, dact, dv);
                 absorb_stage<4, 1>(lane, G.cur, dact, dv);
                 absorb_stage<8, 1>(lane, G.cur, dact, dv);
-                if (dact && dv[0] != 0.0f) grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), dv[0]);
+                const int drow = (dact && dv[0] != 0.0f) ? cache_find<DROWS>(s_dkeys, G.cur) : -1;
+                if (drow >= 0) {
+                    s_dtouch[drow] = (uint8_t)1;
+                    atomicAdd(s_dens + drow, (double)dv[0]);
+                } else if (dact && dv[0] != 0.0f) {
+                    grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), dv[0]);
+                }
             }
             // point gradient of the previous cell
             if (ballot(G.has && G.pg_on) != 0ull) {
@@ -1547,6 +1577,24 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : 3)) void backward_replay_di
         G.has = false;
         G.row = false;
         G.pg_on = false;
+      }
+        it++;
+        if ((it & (kDEpoch - 1u)) == 0u) {
+            block_alive = __syncthreads_or(alive ? 1 : 0) != 0;
+            for (uint32_t e = threadIdx.x; e < (uint32_t)DROWS; e += kBlock) {
+                const uint32_t key = s_dkeys[e];
+                if (key == kNone) continue;
+                if (!block_alive || s_dtouch[e] == (uint8_t)0) {
+                    const float v = (float)s_dens[e];
+                    s_dens[e] = 0.0;
+                    s_dkeys[e] = kNone;
+                    if (v != 0.0f) grad_add(p.attr_grad + (size_t)key * A + (A - 1), v);
+                } else {
+                    s_dtouch[e] = (uint8_t)0;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 

@@ -16,7 +16,17 @@ __global__ __launch_bounds__(256) void scatter(float *buf, size_t n, size_t xcd_
     for (int i = 0; i < kPerLane; ++i) {
         x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
         const size_t a = (size_t)((x * 0x2545F4914F6CDD1Dull) >> 20) % n;
-        if (MODE == 0) unsafeAtomicAdd(dst + a, 1.0f);
+        if (MODE == 3) {
+            // locality: the 64 lanes of a wave hit a 1 KB window (8 lines) that moves every iteration
+            unsigned long long w = __shfl(x, 0, 64);
+            const size_t base = (size_t)((w * 0x2545F4914F6CDD1Dull) >> 20) % (n - 256);
+            unsafeAtomicAdd(buf + base + (a & 255), 1.0f);
+        } else if (MODE == 4) {
+            // strided rows: lane -> its own 112-byte row near a moving window (attr_grad-like)
+            unsigned long long w = __shfl(x, 0, 64);
+            const size_t base = (size_t)((w * 0x2545F4914F6CDD1Dull) >> 20) % (n - 256 * 28);
+            unsafeAtomicAdd(buf + base + (a & 255) * 28 + 27, 1.0f);
+        } else if (MODE == 0) unsafeAtomicAdd(dst + a, 1.0f);
         else if (MODE == 1) __hip_atomic_fetch_add(dst + a, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_fetch_add(dst + a, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
@@ -42,12 +52,12 @@ void run(const char *name, size_t n) {
     const int blocks = 256 * 64;
     const size_t stride = n;
     float *buf, *red; double *tot;
-    hipMalloc(&buf, (MODE == 0 ? 1 : 8) * n * sizeof(float));
+    hipMalloc(&buf, ((MODE == 1 || MODE == 2) ? 8 : 1) * n * sizeof(float));
     hipMalloc(&red, n * sizeof(float));
     hipMalloc(&tot, 8);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 2; ++rep) {
-        hipMemset(buf, 0, (MODE == 0 ? 1 : 8) * n * sizeof(float));
+        hipMemset(buf, 0, ((MODE == 1 || MODE == 2) ? 8 : 1) * n * sizeof(float));
         hipMemset(tot, 0, 8);
         hipDeviceSynchronize();
         hipEventRecord(a);
@@ -57,7 +67,7 @@ void run(const char *name, size_t n) {
     }
     float ms; hipEventElapsedTime(&ms, a, b);
     const float *res = buf;
-    if (MODE != 0) { reduce8<<<(unsigned)((n + 255) / 256), 256>>>(buf, n, stride, red); res = red; }
+    if (MODE == 1 || MODE == 2) { reduce8<<<(unsigned)((n + 255) / 256), 256>>>(buf, n, stride, red); res = red; }
     total<<<1024, 256>>>(res, n, tot);
     double h; hipMemcpy(&h, tot, 8, hipMemcpyDeviceToHost);
     const double ops = (double)blocks * 256 * kPerLane;
@@ -67,12 +77,14 @@ void run(const char *name, size_t n) {
 }
 
 int main() {
-    for (size_t mb : {64, 256}) {
+    for (size_t mb : {256}) {
         const size_t n = mb * 1024 * 1024 / 4;
         printf("-- %zu MB target buffer\n", mb);
         run<0>("agent scope, one buffer", n);
         run<1>("workgroup scope, buffer per XCD", n);
         run<2>("wavefront scope, buffer per XCD", n);
+        run<3>("agent scope, wave hits a moving 1 KB window", n);
+        run<4>("agent scope, 112-B rows near a moving window", n);
     }
     return 0;
 }
