@@ -240,15 +240,31 @@ class Pipeline:
         opts.workspace_bytes = ws.numel()
         opts.foam_prepared = 1 if hit else (2 if topo else 0)
         opts.backward_mode = int(self.backward_mode)
-        # rays given as an image [H, W, 6]: let a wave own an 8x8 pixel tile
-        if len(rays_shape) == 3:
+        # rays given as an image [H, W, 6]: let a wave own an 8x8 pixel tile (a degenerate "image" such
+        # as [B, 1, 6] is a flat batch: tiles of it would be mostly empty)
+        if len(rays_shape) == 3 and rays_shape[0] >= 16 and rays_shape[1] >= 16:
             opts.image_height, opts.image_width = int(rays_shape[0]), int(rays_shape[1])
+        # The workspace is about to be (re)packed by the C call: until that call has succeeded the cache
+        # must not claim it (a failed or never-issued launch would leave an unpacked workspace behind a
+        # valid key).  _foam_done() records it afterwards.
+        opts._pending_foam = None
         if not hit:
-            if self.cache_foam:
-                self._cache.store(tensors)
-            else:
-                self._cache.clear()
+            opts._pending_foam = tensors if self.cache_foam else ()
+            self._cache.key = None
+            if opts.foam_prepared == 0:
+                self._cache.topo_key = None
         return opts
+
+    def _foam_done(self, opts):
+        """The C call that packs the workspace described by `opts` has been issued successfully."""
+        pending = opts._pending_foam
+        if pending is None:
+            return
+        if pending:
+            self._cache.store(pending)
+        else:
+            self._cache.clear()
+        opts._pending_foam = None
 
     def prepare_foam(self, points, attributes, point_adjacency, point_adjacency_offsets):
         """Pack the foam now (rf_prepare_foam) so that the next trace_* call on the same tensors
@@ -263,6 +279,7 @@ class Pipeline:
                     self._sh_degree, self._attr_type, points_c.size(0), _ptr(points_c), _ptr(attributes_c),
                     adjacency_c.numel(), opts.workspace, opts.workspace_bytes, _stream_ptr(points_c.device))
             _lib.check(rc)
+            self._foam_done(opts)
         elif not opts.foam_prepared:
             with torch.cuda.device(points_c.device):
                 rc = self._lib.rf_prepare_foam(
@@ -270,6 +287,7 @@ class Pipeline:
                     adjacency_c.numel(), _ptr(adjacency_c), _ptr(offsets_c), None, opts.workspace,
                     opts.workspace_bytes, _stream_ptr(points_c.device))
             _lib.check(rc)
+            self._foam_done(opts)
 
     # -- hop trail -------------------------------------------------------------------------------
     @staticmethod
@@ -368,6 +386,7 @@ class Pipeline:
                 _ptr(depth_indices), _ptr(num_intersections), _ptr(contribution), C.byref(opts),
                 _stream_ptr(dev))
         _lib.check(rc)
+        self._foam_done(opts)
         if trail is not None:
             foam = (points_c, attributes_c, adjacency_c, offsets_c)
             self._trail = {
@@ -493,6 +512,7 @@ class Pipeline:
                 _ptr(grad_c), _ptr(depth_grad_c), _ptr(ray_error_c), _ptr(ray_grad), _ptr(points_grad),
                 _ptr(attr_grad), _ptr(point_error), C.byref(opts), _stream_ptr(dev))
         _lib.check(rc)
+        self._foam_done(opts)
 
         out = {
             "points_grad": points_grad,
@@ -563,6 +583,7 @@ class Pipeline:
                 _ptr(attributes_c), adjacency_c.numel(), _ptr(adjacency_c), _ptr(offsets_c), _ptr(diff_c),
                 C.byref(cam), _ptr(start_point), _ptr(output_rgba), C.byref(opts), _stream_ptr(dev))
         _lib.check(rc)
+        self._foam_done(opts)
         return None
 
     # -- extras (no reference counterpart) -------------------------------------------------------
@@ -588,6 +609,7 @@ class Pipeline:
                 _ptr(rays_c), _ptr(start_c), 0, None, _ptr(rgba), None, None, None, None,
                 C.byref(opts), _stream_ptr(dev))
         _lib.check(rc)
+        self._foam_done(opts)
         s = stats[:8].cpu().tolist()
         if extra_slots:
             self.last_raw_statistics = stats.cpu()   # experiment builds (scripts/) append records

@@ -459,3 +459,27 @@ def test_shuffled_batch_is_traced_in_a_coherent_order(foam_factory):
     ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
                           fm["point_adjacency_offsets"], rays, starts, depth_quantiles=q)
     np.testing.assert_array_equal(f1["rgba"].cpu().numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+
+
+def test_degenerate_image_shape_is_a_flat_batch(foam_factory):
+    """[B, 1, 6] rays: batch shape is preserved in the outputs, the tile mapping is not used."""
+    d = 2
+    fm = foam_factory(5000, d, 31)
+    rays, starts = H.random_rays(fm, 3000, seed=2)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    r = torch.from_numpy(rays).to(DEV).reshape(3000, 1, 6)
+    s = torch.from_numpy(starts).to(DEV).reshape(3000, 1)
+    pipe = _pipeline(d)
+    assert pipe._launch_opts(p, a, adj, off, r.shape).image_width == 0
+    out = pipe.trace_forward(p, a, adj, off, r, s)
+    assert out["rgba"].shape == (3000, 1, 4) and out["num_intersections"].shape == (3000, 1, 1)
+    ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                          fm["point_adjacency_offsets"], rays, starts)
+    np.testing.assert_array_equal(out["rgba"].cpu().numpy().reshape(3000, 4).view(np.uint32), ref["rgba"].view(np.uint32))
+    g = np.random.default_rng(1).normal(size=(3000, 4)).astype(np.float32)
+    b = pipe.trace_backward(p, a, adj, off, r, s, out["rgba"], torch.from_numpy(g).to(DEV).reshape(3000, 1, 4))
+    refb = O.trace_backward(d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"],
+                            rays, starts, ref["rgba"], g)
+    for k in ("points_grad", "attr_grad"):
+        ok, rel, worst = H.grad_close(b[k].cpu().numpy(), refb[k])
+        assert ok and rel < 1e-5, (k, rel, worst)
