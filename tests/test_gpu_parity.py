@@ -483,3 +483,27 @@ def test_degenerate_image_shape_is_a_flat_batch(foam_factory):
     for k in ("points_grad", "attr_grad"):
         ok, rel, worst = H.grad_close(b[k].cpu().numpy(), refb[k])
         assert ok and rel < 1e-5, (k, rel, worst)
+
+
+def test_ray_order_handles_degenerate_directions(foam_factory):
+    """rf_build_ray_order: zero / non-finite directions get a key like any other ray, the result is a
+    permutation, and tracing such a batch matches the unordered run bit for bit."""
+    d = 0
+    fm = foam_factory(5000, d, 33)
+    rays, starts = H.random_rays(fm, 20_000, seed=4)
+    rays[::97, 3:] = 0.0                      # no direction
+    rays[5::101, 3] = np.inf                  # non-finite
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    r, s = torch.from_numpy(rays).to(DEV), torch.from_numpy(starts).to(DEV)
+    outs = []
+    for reorder in (True, False):
+        pipe = _pipeline(d)
+        pipe.reorder_rays = reorder
+        pipe.reorder_min_rays = 1
+        outs.append(pipe.trace_forward(p, a, adj, off, r, s))
+        if reorder:
+            perm = pipe._order["order"].cpu().numpy().astype(np.int64)
+            assert np.array_equal(np.sort(perm), np.arange(20_000))
+    good = torch.isfinite(outs[1]["rgba"]).all(dim=-1)
+    assert torch.equal(outs[0]["rgba"][good], outs[1]["rgba"][good])
+    assert torch.equal(outs[0]["num_intersections"], outs[1]["num_intersections"])
