@@ -1229,6 +1229,88 @@ __device__ __forceinline__ void cache_flush(double *rows, uint32_t *keys, uint8_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The per-lane state of a trail replay and one hop of it, shared by the replay kernels below.
+// Pipeline registers: id1 = trail[i+1], id0 = trail[i], q0 = cells[id0]; every call of step()
+// issues the loads of hop i+1 / i+2 first and then computes hop i from registers.
+template <int DEG, bool HALF, bool QUANT>
+struct TrailWalker {
+    static constexpr int NB = sh_dim(DEG);
+    BwdRay R;
+    float sh[NB];
+    float4 head, q0;
+    uint32_t cur, hops, recorded, i, n, id0, id1, slot;
+    size_t slots;
+    bool alive;
+
+    __device__ __forceinline__ void init(const BwdParams &p) {
+        uint32_t ray;
+        alive = map_ray(p.grid, ray, slot);
+        const FoamView &fv = p.foam;
+        slots = p.trail_slots;
+        const uint32_t cap = p.trail_cap;
+        init_backward_ray(R);
+        cur = 0;
+        hops = 0;
+        if (alive) {
+            hops = p.trail_hops[slot];
+            if (hops > cap) alive = false;   // did not fit in the trail: left to the re-walk launch
+        }
+        if (alive) load_backward_ray<DEG, HALF>(p, ray, R, cur);
+        sh_basis<DEG>(R.dx, R.dy, R.dz, sh);
+        recorded = hops < cap ? hops : cap;
+        head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        id0 = id1 = 0;
+        if (alive) {
+            head = fv.cells[cur];
+            if (recorded > 0) id0 = p.trail[slot];
+            if (recorded > 1) id1 = p.trail[slots + slot];
+            if (recorded > 0) q0 = fv.cells[id0];
+        }
+        i = 0;
+        n = 0;
+    }
+
+    // one hop of every live lane; G receives the gradients of the segment just crossed (if any)
+    __device__ __forceinline__ void step(const BwdParams &p, StepGrad &G) {
+        const FoamView &fv = p.foam;
+        if (alive) {
+            n++;
+            if (n > p.settings.max_intersections) alive = false;
+        }
+        if (alive && i >= hops) alive = false;   // forward stopped here (no exit face / step cap / opaque)
+        float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t id2 = 0;
+        if (alive) {
+            if (i + 1 < recorded) q1 = fv.cells[id1];
+            if (i + 2 < recorded) id2 = p.trail[(size_t)(i + 2) * slots + slot];
+        }
+        // the face crossed is the bisector of (cur, id0); its fp16 offset is recomputed from the two
+        // cell records exactly as rf_prepare_foam rounds it
+        float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float t1 = 0.0f;
+        if (alive) {
+            nhead = q0;
+            float ox, oy, oz, dp;
+            face_offset(head, nhead, ox, oy, oz);
+            face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
+        }
+        if (alive) {
+            if (t1 > R.t0) {
+                if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
+            }
+            R.t0 = __builtin_fmaxf(R.t0, t1);
+            cur = id0;
+            head = nhead;
+            i++;
+        }
+        id0 = id1;
+        id1 = id2;
+        q0 = q1;
+    }
+};
+
 template <int DEG, bool HALF, bool QUANT>
 __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backward_replay_cached_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
@@ -1246,75 +1328,17 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
     }
     __syncthreads();
 
-    uint32_t ray, slot;
-    bool alive = map_ray(p.grid, ray, slot);
-    const FoamView &fv = p.foam;
-    const size_t slots = p.trail_slots;
-    const uint32_t cap = p.trail_cap;
-
-    BwdRay R;
-    init_backward_ray(R);
-    uint32_t cur = 0;
-    uint32_t hops = 0;
-    if (alive) {
-        hops = p.trail_hops[slot];
-        if (hops > cap) alive = false;
-    }
-    if (alive) load_backward_ray<DEG, HALF>(p, ray, R, cur);
-    float sh[NB];
-    sh_basis<DEG>(R.dx, R.dy, R.dz, sh);
-    const uint32_t max_steps = p.settings.max_intersections;
-    const uint32_t recorded = hops < cap ? hops : cap;
-
-    float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t id0 = 0, id1 = 0;
-    if (alive) {
-        head = fv.cells[cur];
-        if (recorded > 0) id0 = p.trail[slot];
-        if (recorded > 1) id1 = p.trail[slots + slot];
-        if (recorded > 0) q0 = fv.cells[id0];
-    }
+    TrailWalker<DEG, HALF, QUANT> W;
+    W.init(p);
+    const float (&sh)[NB] = W.sh;
 
     StepGrad G;
     clear_step(G);
-    uint32_t i = 0;
-    uint32_t n = 0;
     uint32_t it = 0;
     bool block_alive = true;
     while (block_alive) {
-        if (ballot(alive) != 0ull) {
-            if (alive) {
-                n++;
-                if (n > max_steps) alive = false;
-            }
-            if (alive && i >= hops) alive = false;
-            float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            uint32_t id2 = 0;
-            if (alive) {
-                if (i + 1 < recorded) q1 = fv.cells[id1];
-                if (i + 2 < recorded) id2 = p.trail[(size_t)(i + 2) * slots + slot];
-            }
-            float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            float t1 = 0.0f;
-            if (alive) {
-                nhead = q0;
-                float ox, oy, oz, dp;
-                face_offset(head, nhead, ox, oy, oz);
-                face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
-            }
-            if (alive) {
-                if (t1 > R.t0) {
-                    if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
-                }
-                R.t0 = __builtin_fmaxf(R.t0, t1);
-                cur = id0;
-                head = nhead;
-                i++;
-            }
-            id0 = id1;
-            id1 = id2;
-            q0 = q1;
+        if (ballot(W.alive) != 0ull) {
+            W.step(p, G);
 
             const uint32_t lane = threadIdx.x & 63u;
             if (ballot(G.has) != 0ull) {
@@ -1382,7 +1406,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backwar
         }
         it++;
         if ((it & (kEpoch - 1u)) == 0u) {
-            block_alive = __syncthreads_or(alive ? 1 : 0) != 0;
+            block_alive = __syncthreads_or(W.alive ? 1 : 0) != 0;
             cache_flush<NB>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad);
             __syncthreads();
         }
@@ -1431,73 +1455,15 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : 3)) void backward_replay_di
     uint32_t it = 0;
     bool block_alive = true;
 
-    uint32_t ray, slot;
-    bool alive = map_ray(p.grid, ray, slot);
-    const FoamView &fv = p.foam;
-    const size_t slots = p.trail_slots;
-    const uint32_t cap = p.trail_cap;
-
-    BwdRay R;
-    init_backward_ray(R);
-    uint32_t cur = 0;
-    uint32_t hops = 0;
-    if (alive) {
-        hops = p.trail_hops[slot];
-        if (hops > cap) alive = false;   // did not fit in the trail: left to the re-walk launch
-    }
-    if (alive) load_backward_ray<DEG, HALF>(p, ray, R, cur);
-    float sh[NB];
-    sh_basis<DEG>(R.dx, R.dy, R.dz, sh);
-    const uint32_t max_steps = p.settings.max_intersections;
-    const uint32_t recorded = hops < cap ? hops : cap;
-
-    float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t id0 = 0, id1 = 0;
-    if (alive) {
-        head = fv.cells[cur];
-        if (recorded > 0) id0 = p.trail[slot];
-        if (recorded > 1) id1 = p.trail[slots + slot];
-        if (recorded > 0) q0 = fv.cells[id0];
-    }
+    TrailWalker<DEG, HALF, QUANT> W;
+    W.init(p);
+    const float (&sh)[NB] = W.sh;
 
     StepGrad G;
     clear_step(G);
-    uint32_t i = 0;
-    uint32_t n = 0;
     while (block_alive) {
-      if (ballot(alive) != 0ull) {
-        if (alive) {
-            n++;
-            if (n > max_steps) alive = false;
-        }
-        if (alive && i >= hops) alive = false;
-        float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint32_t id2 = 0;
-        if (alive) {
-            if (i + 1 < recorded) q1 = fv.cells[id1];
-            if (i + 2 < recorded) id2 = p.trail[(size_t)(i + 2) * slots + slot];
-        }
-        float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float t1 = 0.0f;
-        if (alive) {
-            nhead = q0;
-            float ox, oy, oz, dp;
-            face_offset(head, nhead, ox, oy, oz);
-            face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
-        }
-        if (alive) {
-            if (t1 > R.t0) {
-                if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
-            }
-            R.t0 = __builtin_fmaxf(R.t0, t1);
-            cur = id0;
-            head = nhead;
-            i++;
-        }
-        id0 = id1;
-        id1 = id2;
-        q0 = q1;
+      if (ballot(W.alive) != 0ull) {
+        W.step(p, G);
 
         if (ballot(G.has) != 0ull) {
             // density gradient: lanes of the wave in the same cell merged (DPP xor stages), then one
@@ -1580,7 +1546,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : 3)) void backward_replay_di
       }
         it++;
         if ((it & (kDEpoch - 1u)) == 0u) {
-            block_alive = __syncthreads_or(alive ? 1 : 0) != 0;
+            block_alive = __syncthreads_or(W.alive ? 1 : 0) != 0;
             for (uint32_t e = threadIdx.x; e < (uint32_t)DROWS; e += kBlock) {
                 const uint32_t key = s_dkeys[e];
                 if (key == kNone) continue;
