@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 //   * lanes of a wave in the same cell are first merged in registers (DPP xor stages), which cuts
 //     the lanes per address;
 //   * rows of doubles are large (248 B at SH degree 2: 160 rows in the 40 KB a block may use at 4
-//     blocks per CU), so the table is flushed often: every kEpoch steps the block synchronises and
+//     blocks per CU; 424 B at degree 3: 124 rows at 3 blocks per CU), so the table is flushed often: every kEpoch steps the block synchronises and
 //     evicts the rows that were not touched during the epoch (the walk has moved past those cells)
 //     with one coalesced row of global atomics each, skipping zeros; rows still in use stay.
 //     A lane whose key finds no free row adds straight to global memory instead (must stay rare:
@@ -1145,6 +1145,12 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 #endif
 #ifndef RF_BWD_WAVES
 #define RF_BWD_WAVES 4
+#endif
+#ifndef RF_CACHE_ROWS_D3
+#define RF_CACHE_ROWS_D3 124
+#endif
+#ifndef RF_BWD_WAVES_D3
+#define RF_BWD_WAVES_D3 3
 #endif
 #ifndef RF_DTABLE_ROWS
 #define RF_DTABLE_ROWS 768
@@ -1178,7 +1184,7 @@ struct CacheLayout {
     static constexpr int COL_PG = NCOEF + 1;
     static constexpr int NCOL = NCOEF + 4;
     static constexpr int STRIDE = NCOL | 1;   // odd number of doubles: columns spread over the banks
-    static constexpr int ROWS = NB == 1 ? 256 : (NB == 4 ? 256 : (NB == 9 ? RF_CACHE_ROWS_D2 : 176));
+    static constexpr int ROWS = NB == 1 ? 256 : (NB == 4 ? 256 : (NB == 9 ? RF_CACHE_ROWS_D2 : RF_CACHE_ROWS_D3));
 };
 
 template <int ROWS>
@@ -1318,7 +1324,7 @@ struct TrailWalker {
 };
 
 template <int DEG, bool HALF, bool QUANT>
-__global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : 2)) void backward_replay_cached_kernel(BwdParams p) {
+__global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)) void backward_replay_cached_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
     constexpr int A = 1 + 3 * NB;
     using L = CacheLayout<NB>;
