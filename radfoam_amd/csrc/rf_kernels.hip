@@ -403,7 +403,10 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 // instances up to SH degree 2 -- measured 3 % faster than leaving the choice to the compiler, which
 // lands on the same occupancy with a worse schedule -- and 4 where quantile / statistics code or the
 // 16 SH basis values of degree 3 would spill at 80.
-constexpr int forward_waves(int deg, bool quant, bool stats) { return (deg <= 2 && !quant && !stats) ? 6 : 4; }
+#ifndef RF_FWD_WAVES_OTHER
+#define RF_FWD_WAVES_OTHER 4
+#endif
+constexpr int forward_waves(int deg, bool quant, bool stats) { return (deg <= 2 && !quant && !stats) ? 6 : RF_FWD_WAVES_OTHER; }
 
 template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS>
 __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forward_kernel(FwdParams p) {
