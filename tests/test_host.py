@@ -71,6 +71,36 @@ def test_host_only_entry_points():
     assert rc == -1 and "null pointer" in _lib.last_error()
 
 
+def test_scene_side_entry_points_validate_without_a_device():
+    """The widened entry points report argument errors before any launch; their workspace
+    sizes are host-side arithmetic."""
+    from radfoam_amd import _lib
+
+    lib = _lib.load()
+    assert lib.rf_pack_attributes(7, 0, 10, None, None, None, 1.0, None, None) == -1
+    assert "Unsupported SH degree" in _lib.last_error()
+    assert lib.rf_pack_attributes(2, 0, 10, None, None, None, 1.0, None, None) == -1
+    assert "null pointer" in _lib.last_error()
+    assert lib.rf_pack_attributes(2, 0, 0, None, None, None, 1.0, None, None) == 0        # nothing to do
+    assert lib.rf_pack_attributes_backward(2, 10, None, 1.0, None, None, None, None, None) == -1
+    assert lib.rf_nearest_point(None, 0, None, 0, None, None, None) == 0                   # no queries
+    assert lib.rf_nearest_point(None, 0, None, 3, None, None, None) == -1 and "no points" in _lib.last_error()
+    assert lib.rf_farthest_neighbor(None, 5, None, None, None, None, None) == -1
+    assert lib.rf_build_ray_order(None, None, 0, None, None, 0, None) == 0
+    assert lib.rf_build_ray_order(None, None, 8, None, None, 0, None) == -1
+    n = lib.rf_ray_order_workspace_bytes(1_000_000)
+    assert n >= 1_000_000 * (8 + 8 + 4)                  # two key buffers + an index buffer, + sort scratch
+    m = lib.rf_adjacency_workspace_bytes(1000)
+    assert m >= 2 * 12 * 1000 * 8                        # two buffers of 12 directed edge keys per tet
+    assert lib.rf_build_adjacency(None, 5, 10, None, None, None, None, 0, None) == -1
+    # a real-looking call with a workspace that is too small is refused with the workspace status
+    dummy = (ctypes.c_uint32 * 64)()
+    rc = lib.rf_build_adjacency(dummy, 1, 10, dummy, dummy, dummy, dummy, 16, None)
+    assert rc == -2 and "workspace" in _lib.last_error()
+    rc = lib.rf_build_ray_order(ctypes.cast(dummy, ctypes.c_void_p), dummy, 8, dummy, dummy, 16, None)
+    assert rc == -2 and "workspace" in _lib.last_error()
+
+
 def test_create_pipeline_dtype_and_degree_rules():
     import radfoam
 
