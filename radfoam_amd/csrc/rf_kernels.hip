@@ -116,13 +116,15 @@ constexpr int kBlock = 256;
 // block -> tile, lane -> ray
 
 // The dispatcher places block b on XCD b%8, and every XCD has a private L2.  Tiles are dealt to
-// the XCDs in chunks of `chunk` consecutive tiles of the row-major tile order (half an image row of
-// tiles): XCD x works through chunks x, x+8, x+16, ...  A chunk is a contiguous strip of the image
-// (one slab of the foam for that XCD's L2); dealing them round-robin gives every XCD strips from
-// all over the image, so that the XCDs finish together even though rays through different image
-// regions walk very different numbers of cells (measured: contiguous eighths of the image finish
-// between 5.8 and 7.7 ms).  The launch is padded to whole rounds of 8 chunks; blocks whose tile
-// falls past the end own no rays.
+// the XCDs in chunks of `chunk` consecutive tiles of the row-major tile order (a quarter of an image
+// row of tiles), a round of 8 chunks at a time.  A chunk is a contiguous strip of the image (one slab
+// of the foam for that XCD's L2); dealing them gives every XCD strips from all over the image, so
+// that the XCDs finish together even though rays through different image regions walk very
+// different numbers of cells (measured: contiguous eighths of the image finish between 5.8 and
+// 7.7 ms).  Which chunk of a round an XCD takes rotates from round to round: with a fixed assignment
+// and k chunks per image row, XCD x would only ever see the same (x mod k)-th part of every row
+// (measured with 16x4-tile blocks, 8 per row: one XCD per image column, 7.7 ms instead of 5.6).
+// The launch is padded to whole rounds of 8 chunks; blocks whose tile falls past the end own no rays.
 __device__ __forceinline__ uint32_t dealt_tile(uint32_t b, uint32_t chunk, uint32_t rounds) {
     const uint32_t x = b & 7u, i = b >> 3;
     uint32_t j = i / chunk;
@@ -131,7 +133,7 @@ __device__ __forceinline__ uint32_t dealt_tile(uint32_t b, uint32_t chunk, uint3
     // the blocks still running when the launch drains are then neighbours in the image, of
     // similar length, instead of the longest walks of the frame
     j = (j & 1u) ? rounds - 1u - (j >> 1) : (j >> 1);
-    return (j * 8u + x) * chunk + o;
+    return (j * 8u + ((x + 3u * j) & 7u)) * chunk + o;
 }
 
 inline __host__ __device__ uint32_t num_tiles(const RayGrid &g) {
@@ -142,7 +144,7 @@ inline __host__ __device__ uint32_t num_tiles(const RayGrid &g) {
 inline __host__ __device__ uint32_t tile_chunk(const RayGrid &g) {
     if (g.img_w) {
         const uint32_t tiles_x = (g.img_w + 15u) >> 4;
-        return tiles_x > 1u ? (tiles_x + 1u) >> 1 : 1u;
+        return tiles_x > 3u ? (tiles_x + 3u) >> 2 : 1u;
     }
     return 16u;
 }
