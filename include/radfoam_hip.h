@@ -86,6 +86,10 @@ typedef struct rf_launch_opts {
     /* every input and output stays indexed by the caller's ray index.  The same order must be given   */
     /* to the rf_trace_backward call that replays a trail.                                             */
     const uint32_t *ray_order;
+    /* rf_trace_forward with `stats` only, optional: device uint8[num_points]; byte i is set to 1 when  */
+    /* any ray scans cell i (the caller zeroes it).  Feeds the compulsory-traffic floor of bench.py's   */
+    /* roofline: bytes of the distinct cells, face lists and colour rows a frame touches at least once. */
+    uint8_t *visit_marks;
 } rf_launch_opts;
 
 /* Last error message of the calling thread ("" if none). */
@@ -230,6 +234,27 @@ int rf_build_adjacency(const uint32_t *tets, uint32_t num_tets, uint32_t num_poi
                        uint32_t *point_adjacency, uint32_t *point_adjacency_offsets,
                        uint32_t *point_adjacency_size, void *workspace, size_t workspace_bytes,
                        void *stream);
+
+/* ---- multi-GPU gradient exchange (radfoam_amd/dist.py; no counterpart: the reference is single-GPU) ---- */
+
+/* Floats per packed gradient row: 1 (cell index, as bits) + 3 (points_grad) + A (attr_grad), rounded up to
+ * a multiple of 4 (16-byte rows). */
+uint32_t rf_grad_row_pitch(uint32_t attr_dim);
+
+/* Compacts the rows of the gradient buffers that hold anything: for every cell i with a non-zero value among
+ * points_grad[i][0..3) and attr_grad[i][0..A), appends {i, points_grad[i], attr_grad[i]} to `packed`
+ * ([capacity][rf_grad_row_pitch(A)] floats, row order unspecified).  *count (DEVICE uint32, zeroed by the
+ * caller) receives the number of such rows even when it exceeds `capacity` (rows past the capacity are not
+ * written: the caller re-runs with a larger buffer).  A row-sharded frame touches only the cells its own
+ * rays cross, so ranks exchange these rows instead of all-reducing the dense N*(3+A) buffer. */
+int rf_compact_grad_rows(const float *points_grad, const float *attr_grad, uint32_t num_points,
+                         uint32_t attr_dim, uint32_t capacity, uint32_t *count, float *packed, void *stream);
+
+/* Applies `num_rows` packed rows to the dense buffers: mode 0 adds every row to points_grad / attr_grad at its
+ * cell index; mode 1 zeroes those rows instead.  The cell indices of one call must be distinct (they are: one
+ * rank's compaction lists a cell once), so calls issued in rank order give the same sums on every rank. */
+int rf_scatter_grad_rows(const float *packed, uint32_t num_rows, uint32_t num_points, uint32_t attr_dim,
+                         int mode, float *points_grad, float *attr_grad, void *stream);
 
 #ifdef __cplusplus
 }

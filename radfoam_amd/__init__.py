@@ -7,7 +7,7 @@ include/radfoam_hip.h; everything else the reference module exports is a torch/s
 (radfoam_amd/shims.py).  ``import radfoam`` resolves to this package through the alias
 package ``radfoam/`` at the repo root.
 """
-from .pipeline import Pipeline, create_pipeline
+from .pipeline import Pipeline, create_pipeline, invalidate_caches
 from .scene_ops import pack_attributes
 from .shims import (BatchFetcher, Triangulation, TriangulationFailedError, Viewer, build_aabb_tree,
                     farthest_neighbor, nn, run_with_viewer)
@@ -15,4 +15,5 @@ from .shims import (BatchFetcher, Triangulation, TriangulationFailedError, Viewe
 __all__ = [
     "Pipeline", "create_pipeline", "Triangulation", "TriangulationFailedError", "build_aabb_tree",
     "nn", "farthest_neighbor", "BatchFetcher", "Viewer", "run_with_viewer", "pack_attributes",
+    "invalidate_caches",
 ]

@@ -55,6 +55,7 @@ class LaunchOpts(C.Structure):
         ("trail_cap", C.c_uint32),
         ("trail_slots", C.c_uint32),
         ("ray_order", C.c_void_p),
+        ("visit_marks", C.c_void_p),
     ]
 
 
@@ -83,6 +84,9 @@ SYMBOLS = {
     "rf_build_ray_order": (_INT, [_P, _P, _U32, _P, _P, C.c_size_t, _P]),
     "rf_adjacency_workspace_bytes": (C.c_size_t, [_U32]),
     "rf_build_adjacency": (_INT, [_P, _U32, _U32, _P, _P, _P, _P, C.c_size_t, _P]),
+    "rf_grad_row_pitch": (_U32, [_U32]),
+    "rf_compact_grad_rows": (_INT, [_P, _P, _U32, _U32, _U32, _P, _P, _P]),
+    "rf_scatter_grad_rows": (_INT, [_P, _U32, _U32, _U32, _INT, _P, _P, _P]),
     "rf_trace_benchmark": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _P,
                                   C.POINTER(Camera), _P, _P, C.POINTER(LaunchOpts), _P]),
 }

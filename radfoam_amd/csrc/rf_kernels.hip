@@ -78,6 +78,7 @@ struct FwdParams {
     uint32_t *nint;
     float *contribution;
     unsigned long long *stats;
+    uint8_t *visit_marks;   // statistics instance only, optional: [N] set to 1 for every cell scanned
     uint32_t *trail;        // [trail_cap][trail_slots] cell entered by each hop (optional)
     uint32_t *trail_hops;   // [trail_slots] hops taken by the ray of each thread slot
     uint32_t trail_cap, trail_slots;
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
             if (want_stats) {
                 st_cells++;
                 st_faces += fv.offsets[cur + 1] - fv.offsets[cur];
+                if (p.visit_marks) p.visit_marks[cur] = (uint8_t)1;
             }
             if (sr.k == kNone) alive = false;
         }
@@ -2032,9 +2034,10 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     if (!valid_instance(sh_degree, attr_type))
         return fail(RF_ERR_INVALID_ARGUMENT, "Unsupported SH degree or attribute type");
     if (!settings || !opts) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: settings/opts null");
-    if (num_rays == 0) return RF_OK;
-    if (!points || !attributes || !point_adjacency || !point_adjacency_offsets || !rays ||
-        !start_point_index || !ray_rgba)
+    // An empty batch launches no walk, but the workspace is still packed below: whatever num_rays is,
+    // after a successful call the workspace describes these inputs (callers cache on that).
+    if (!points || !attributes || !point_adjacency || !point_adjacency_offsets ||
+        (num_rays != 0 && (!rays || !start_point_index || !ray_rgba)))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_depths || !quantile_point_indices))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: depth quantile buffers missing");
@@ -2049,6 +2052,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
                               opts->workspace_bytes, s, opts->foam_prepared == 2u);
         if (rc != RF_OK) return rc;
     }
+    if (num_rays == 0) return RF_OK;
     FwdParams p{};
     p.foam = make_view(L, opts->workspace, attributes, point_adjacency_offsets);
     p.grid = make_grid(num_rays, opts);
@@ -2063,6 +2067,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     p.nint = num_intersections;
     p.contribution = static_cast<float *>(point_contribution);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
+    p.visit_marks = opts->stats ? opts->visit_marks : nullptr;
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: trail_slots smaller than rf_trail_slots()");
@@ -2088,9 +2093,9 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     if (!valid_instance(sh_degree, attr_type))
         return fail(RF_ERR_INVALID_ARGUMENT, "Unsupported SH degree or attribute type");
     if (!settings || !opts) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: settings/opts null");
-    if (num_rays == 0) return RF_OK;
-    if (!points || !attributes || !point_adjacency || !point_adjacency_offsets || !rays ||
-        !start_point_index || !ray_rgba || !ray_rgba_grad || !points_grad || !attribute_grad)
+    if (!points || !attributes || !point_adjacency || !point_adjacency_offsets ||
+        (num_rays != 0 && (!rays || !start_point_index || !ray_rgba || !ray_rgba_grad || !points_grad ||
+                           !attribute_grad)))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_point_indices || !depth_grad))
         return fail(RF_ERR_INVALID_ARGUMENT, "depth_grad must be provided if depth_quantiles is provided");
@@ -2107,6 +2112,7 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
                               opts->workspace_bytes, s, opts->foam_prepared == 2u);
         if (rc != RF_OK) return rc;
     }
+    if (num_rays == 0) return RF_OK;   // workspace packed above, nothing to walk
     BwdParams p{};
     p.foam = make_view(L, opts->workspace, attributes, point_adjacency_offsets);
     p.grid = make_grid(num_rays, opts);
@@ -2152,9 +2158,9 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
     if (!settings || !opts || !camera)
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_benchmark: settings/opts/camera null");
     if (camera->model > 1u) return fail(RF_ERR_INVALID_ARGUMENT, "Invalid camera model");
-    if (camera->width == 0 || camera->height == 0) return RF_OK;
+    const bool no_pixels = camera->width == 0 || camera->height == 0;
     if (!points || !attributes || !point_adjacency || !point_adjacency_offsets || !adjacent_diff ||
-        !start_point_index || !ray_rgba)
+        (!no_pixels && (!start_point_index || !ray_rgba)))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_benchmark: null pointer");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2168,6 +2174,7 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
                               opts->workspace_bytes, s);
         if (rc != RF_OK) return rc;
     }
+    if (no_pixels) return RF_OK;   // workspace packed above (as for an empty ray batch)
     FwdParams p{};
     p.foam = make_view(L, opts->workspace, attributes, point_adjacency_offsets);
     p.grid = RayGrid{camera->width * camera->height, camera->width, camera->height, nullptr};

@@ -126,8 +126,18 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&sh)[
 // (nx, ny, nz) / den with one shared reciprocal: the instruction sequence hipcc expands each IEEE
 // fp32 divide into (v_rcp_f32, one Newton step on the reciprocal, two residual corrections of the
 // quotient) without v_div_scale / v_div_fmas / v_div_fixup, which only act when an operand or the
-// quotient is subnormal, huge, zero, infinite or NaN.  Bit-identical to three '/' otherwise.
+// quotient is subnormal, huge, zero, infinite or NaN.  Bit-identical to three '/' otherwise; a
+// denominator outside the range where that holds takes the plain divides.
 __device__ __forceinline__ void div3(float nx, float ny, float nz, float den, float &qx, float &qy, float &qz) {
+    // |den| outside [2^-60, 2^60] (or zero, subnormal, inf, NaN): the scaling steps that sequence
+    // leaves out would act, so take the IEEE divide itself.  Reached e.g. with weight_threshold = 0,
+    // where the transmittance in the compositing denominators decays into the subnormal range.
+    if (((f2bits(den) >> 23) & 0xFFu) - 67u > 120u) {
+        qx = nx / den;
+        qy = ny / den;
+        qz = nz / den;
+        return;
+    }
     float y = __builtin_amdgcn_rcpf(den);
     float e = fma_(-den, y, 1.0f);
     y = fma_(e, y, y);

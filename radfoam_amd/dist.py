@@ -11,7 +11,14 @@ largest BASELINE config) is replicated on every GPU; a batch of rays shaped [H, 
     fp32 buffer (Pipeline.trace_backward()["flat_grad"]), so a step costs a single SUM
     all-reduce (N*(3+A)*4 bytes: 248 MB for the 2M-point SH-2 foam).  On the fully connected
     xGMI mesh RCCL runs this as reduce-scatter + all-gather over all 7 links of every GPU;
-  * ``contribution`` / ``point_error`` ([N,1]) are summed the same way when requested.
+  * ``contribution`` / ``point_error`` ([N,1]) are summed the same way when requested;
+  * the row blocks of ONE image touch nearly disjoint wedges of the foam, so each rank's dense buffer
+    is almost all zeros: ``SparseGradExchange`` all-gathers only the rows that hold anything (a few MB
+    per rank) and adds them in rank order -- bit-identical sums on every rank at a fraction of the
+    dense all-reduce's xGMI traffic (DESIGN.md section 5 has the arithmetic);
+  * rays through different parts of a frame walk very different numbers of cells, so equal row counts
+    are not equal work: ``balanced_row_blocks`` cuts the rows by measured cost (the previous step's
+    ``num_intersections``).
 
 Backend "nccl" (= RCCL on ROCm) on GPUs; the same code runs on "gloo" with CPU tensors, which
 is how tests/test_dist.py covers it without a GPU.
@@ -31,13 +38,58 @@ def row_block(num_rows: int, rank: int, world_size: int):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def shard_rows(tensor: torch.Tensor, rank: int | None = None, world_size: int | None = None, dim: int = 0):
-    """This rank's row block of a per-ray tensor (rays, start_point, depth_quantiles, targets)."""
+def balanced_row_blocks(row_cost, world_size: int, align: int = 8):
+    """Cut ``len(row_cost)`` rows into ``world_size`` contiguous blocks of (nearly) equal total cost.
+
+    ``row_cost[y]`` is any non-negative measure of the work of image row y -- bench.py and
+    ``ShardedTracer.rebalance`` use the cells the row's rays visited in the previous step.  Block
+    boundaries are multiples of ``align`` rows (a wave owns an 8x8 pixel tile; every block still
+    gets at least one such band).  Returns ``world_size + 1`` ascending boundaries, first 0, last the row count.
+    Contiguous blocks, not interleaved bands: the cells a block's rays cross are then a compact wedge of
+    the foam, which is what keeps the sparse gradient exchange small."""
+    cost = [float(c) for c in row_cost]
+    rows = len(cost)
+    if world_size <= 0:
+        raise ValueError("invalid world_size")
+    align = max(1, int(align))
+    bands = (rows + align - 1) // align
+    if bands < world_size:          # too few rows to give everyone an aligned band: plain even split
+        return [row_block(rows, r, world_size)[0] for r in range(world_size)] + [rows]
+    band_cost = [sum(cost[b * align:(b + 1) * align]) for b in range(bands)]
+    total = sum(band_cost)
+    if not total > 0.0:
+        band_cost = [1.0] * bands
+        total = float(bands)
+    bounds = [0]
+    acc, b = 0.0, 0
+    for r in range(1, world_size):
+        target = total * r / world_size
+        # advance while taking the next band brings the running cost closer to the target; always leave
+        # enough bands for the blocks still to be cut and take at least one
+        lo = bounds[-1] + 1
+        hi = bands - (world_size - r)
+        while b < hi and (b < lo or abs(acc + band_cost[b] - target) <= abs(acc - target)):
+            acc += band_cost[b]
+            b += 1
+        bounds.append(b)
+    bounds.append(bands)
+    return [min(x * align, rows) for x in bounds]
+
+
+def shard_rows(tensor: torch.Tensor, rank: int | None = None, world_size: int | None = None, dim: int = 0,
+               bounds=None):
+    """This rank's row block of a per-ray tensor (rays, start_point, depth_quantiles, targets).
+    ``bounds``: boundaries from ``balanced_row_blocks`` instead of the even split."""
     if world_size is None:
         world_size = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    b, e = row_block(tensor.size(dim), rank, world_size)
+    if bounds is not None:
+        if len(bounds) != world_size + 1 or bounds[-1] != tensor.size(dim):
+            raise ValueError("row bounds do not match the tensor / world size")
+        b, e = bounds[rank], bounds[rank + 1]
+    else:
+        b, e = row_block(tensor.size(dim), rank, world_size)
     return tensor.narrow(dim, b, e - b)
 
 
@@ -73,13 +125,16 @@ def all_reduce_statistic(t: torch.Tensor, group=None):
     return t
 
 
-def gather_rows(local: torch.Tensor, num_rows: int, group=None, dim: int = 0) -> torch.Tensor:
+def gather_rows(local: torch.Tensor, num_rows: int, group=None, dim: int = 0, bounds=None) -> torch.Tensor:
     """Concatenate the ranks' row blocks (e.g. rgba [h_g, W, 4]) into the full [H, W, 4] tensor on
-    every rank.  Row blocks may differ by one row, so shorter blocks are padded for the gather."""
+    every rank.  Row blocks may differ in height, so shorter blocks are padded for the gather."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
-    sizes = [row_block(num_rows, r, world) for r in range(world)]
+    if bounds is not None:
+        sizes = [(bounds[r], bounds[r + 1]) for r in range(world)]
+    else:
+        sizes = [row_block(num_rows, r, world) for r in range(world)]
     longest = max(e - b for b, e in sizes)
     pad_shape = list(local.shape)
     pad_shape[dim] = longest
@@ -90,18 +145,187 @@ def gather_rows(local: torch.Tensor, num_rows: int, group=None, dim: int = 0) ->
     return torch.cat([p.narrow(dim, 0, e - b) for p, (b, e) in zip(parts, sizes)], dim=dim)
 
 
+class SparseGradExchange:
+    """SUM of the ranks' partial gradients by exchanging only the rows that hold anything.
+
+    ``reduce(result)`` takes what ``Pipeline.trace_backward`` returned (the flat fp32
+    ``[points_grad | attr_grad]`` buffer and its two views) and leaves, in place and on every rank, the sum
+    over ranks -- what ``all_reduce_gradients`` computes with a dense all-reduce -- in three moves:
+
+      1. compact: one pass over the dense buffer lists the cells with a non-zero gradient and packs their
+         rows ``{cell, points_grad[3], attr_grad[A]}`` (rf_compact_grad_rows);
+      2. all-gather the row counts (one small collective, read back on the host: the only synchronisation)
+         and then the packed rows, padded to the longest list (one collective, a few MB per rank);
+      3. every rank zeroes its own listed rows and adds all ranks' rows IN RANK ORDER
+         (rf_scatter_grad_rows): the same additions in the same order everywhere, so the ranks' sums --
+         and the parameters an identical optimiser step derives from them -- are bit-identical, which a
+         ring all-reduce does not promise.
+
+    Traffic per rank: (world - 1) * longest list * (4 + A) * 4 bytes in, against 2 * (world - 1) / world *
+    N * (3 + A) * 4 for the dense all-reduce.  It pays when the ranks' rays cross mostly different cells:
+    the row blocks of one image (each rank touches ~1/world of the frame's cells); for a shuffled training
+    batch every rank touches everything and the dense all-reduce is the better tool -- ``reduce`` falls
+    back to it by itself when the lists cover more than ``dense_fraction`` of the points.
+
+    CUDA tensors go through the HIP kernels; CPU tensors (the gloo tests) through the same steps written
+    with torch indexing."""
+
+    def __init__(self, group=None, dense_fraction: float = 0.25, growth: float = 1.25):
+        self.group = group
+        self.dense_fraction = float(dense_fraction)
+        self.growth = float(growth)
+        self._send = None
+        self._recv = None
+        #: rows sent by each rank in the last reduce() (host ints), None when it fell back to dense
+        self.last_counts = None
+
+    # -- the two device steps, HIP for CUDA tensors / torch indexing for CPU tensors ---------------
+    @staticmethod
+    def _pitch(a: int) -> int:
+        return (1 + 3 + a + 3) // 4 * 4
+
+    def _compact(self, points_grad, attr_grad, send, count):
+        n, a = attr_grad.shape
+        if points_grad.is_cuda:
+            from . import _lib
+            lib = _lib.load()
+            with torch.cuda.device(points_grad.device):
+                rc = lib.rf_compact_grad_rows(points_grad.data_ptr(), attr_grad.data_ptr(), n, a, send.shape[0],
+                                              count.data_ptr(), send.data_ptr(),
+                                              torch.cuda.current_stream(points_grad.device).cuda_stream)
+            _lib.check(rc)
+            return
+        touched = ((points_grad != 0).any(dim=1) | (attr_grad != 0).any(dim=1)).nonzero().reshape(-1)
+        k = int(touched.numel())
+        count.fill_(k)
+        k = min(k, send.shape[0])
+        idx = touched[:k]
+        send[:k, 0] = idx.to(torch.int32).view(torch.float32)
+        send[:k, 1:4] = points_grad[idx]
+        send[:k, 4:4 + a] = attr_grad[idx]
+        send[:k, 4 + a:] = 0
+
+    @staticmethod
+    def _scatter(rows, k, points_grad, attr_grad, zero):
+        if k == 0:
+            return
+        n, a = attr_grad.shape
+        if points_grad.is_cuda:
+            from . import _lib
+            lib = _lib.load()
+            with torch.cuda.device(points_grad.device):
+                rc = lib.rf_scatter_grad_rows(rows.data_ptr(), k, n, a, 1 if zero else 0, points_grad.data_ptr(),
+                                              attr_grad.data_ptr(),
+                                              torch.cuda.current_stream(points_grad.device).cuda_stream)
+            _lib.check(rc)
+            return
+        idx = rows[:k, 0].contiguous().view(torch.int32).to(torch.int64)
+        if zero:
+            points_grad[idx] = 0
+            attr_grad[idx] = 0
+        else:
+            points_grad[idx] += rows[:k, 1:4]
+            attr_grad[idx] += rows[:k, 4:4 + a]
+
+    def _buffers(self, cap, world, pitch, like):
+        if self._send is None or self._send.shape != (cap, pitch) or self._send.device != like.device:
+            self._send = torch.empty((cap, pitch), dtype=torch.float32, device=like.device)
+            self._recv = torch.empty((world * cap, pitch), dtype=torch.float32, device=like.device)
+        return self._send, self._recv
+
+    def reduce(self, backward_result: dict):
+        """In place; returns ``backward_result``."""
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return backward_result
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        pg, ag = backward_result["points_grad"], backward_result["attr_grad"]
+        flat = backward_result.get("flat_grad")
+        if flat is None or ag.dtype != torch.float32 or ag.data_ptr() != flat.data_ptr() + pg.numel() * 4:
+            all_reduce_gradients(backward_result, group=self.group)     # fp16 pipelines: converted attr_grad
+            self.last_counts = None
+            return backward_result
+        n, a = ag.shape
+        pitch = self._pitch(a)
+        cap = self._send.shape[0] if self._send is not None else max(1024, n // (4 * world))
+        count = torch.zeros(1, dtype=torch.int32, device=pg.device)
+        counts_dev = torch.empty(world, dtype=torch.int32, device=pg.device)
+        while True:
+            send, recv = self._buffers(cap, world, pitch, pg)
+            count.zero_()
+            self._compact(pg, ag, send, count)
+            dist.all_gather_into_tensor(counts_dev, count, group=self.group)
+            counts = [int(c) for c in counts_dev.tolist()]      # the one host synchronisation of a step
+            longest = max(counts)
+            if longest <= cap:
+                break
+            cap = int(longest * self.growth) + 1                # every rank sees the same counts: same decision
+        if sum(counts) > self.dense_fraction * n * world or longest == 0:
+            if longest:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.last_counts = None if longest else counts
+            pe = backward_result.get("point_error")
+            if pe is not None:
+                dist.all_reduce(pe, op=dist.ReduceOp.SUM, group=self.group)
+            return backward_result
+        dist.all_gather_into_tensor(recv[: world * longest], send[:longest], group=self.group)
+        got = recv[: world * longest].view(world, longest, pitch)
+        self._scatter(send, counts[rank], pg, ag, zero=True)
+        for r in range(world):
+            self._scatter(got[r], counts[r], pg, ag, zero=False)
+        pe = backward_result.get("point_error")
+        if pe is not None:
+            dist.all_reduce(pe, op=dist.ReduceOp.SUM, group=self.group)
+        self.last_counts = counts
+        return backward_result
+
+
 class ShardedTracer:
     """Row-sharded forward/backward around a Pipeline: every rank calls it with the FULL ray
     tensors and receives its own rows' outputs; ``backward`` returns gradients already summed
-    over ranks (identical on all ranks, ready for an identical optimiser step)."""
+    over ranks (identical on all ranks, ready for an identical optimiser step).
 
-    def __init__(self, pipeline, group=None):
+    ``exchange``: "sparse" (SparseGradExchange, default: rows of one image touch nearly disjoint cells)
+    or "dense" (one SUM all-reduce of the flat buffer).  ``rebalance(num_intersections_local)`` re-cuts
+    the row blocks by the cost the last forward measured."""
+
+    def __init__(self, pipeline, group=None, exchange: str = "sparse"):
+        if exchange not in ("sparse", "dense"):
+            raise ValueError("exchange must be 'sparse' or 'dense'")
         self.pipeline = pipeline
         self.group = group
+        self.bounds = None
+        self.sparse = SparseGradExchange(group) if exchange == "sparse" else None
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _rank(self):
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
 
     def _shard(self, t):
-        return None if t is None else shard_rows(t, dist.get_rank(self.group) if dist.is_initialized() else 0,
-                                                 dist.get_world_size(self.group) if dist.is_initialized() else 1)
+        return None if t is None else shard_rows(t, self._rank(), self._world(), bounds=self.bounds)
+
+    def rows(self, num_rows: int):
+        """[begin, end) of this rank's rows of an image with ``num_rows`` rows."""
+        if self.bounds is not None:
+            return self.bounds[self._rank()], self.bounds[self._rank() + 1]
+        return row_block(num_rows, self._rank(), self._world())
+
+    def rebalance(self, num_intersections_local: torch.Tensor, num_rows: int, align: int = 8):
+        """Re-cut the row blocks so that every rank gets the same number of visited cells, from the
+        ``num_intersections`` ([h_local, W, 1]) the last forward returned for this rank's rows.  One small
+        all-gather; every rank computes the same boundaries.  Returns them."""
+        world = self._world()
+        if world == 1:
+            self.bounds = None
+            return [0, num_rows]
+        cost_local = num_intersections_local.reshape(num_intersections_local.shape[0], -1).to(torch.int64).sum(dim=1)
+        b, e = self.rows(num_rows)
+        full = torch.zeros(num_rows, dtype=torch.int64, device=cost_local.device)
+        full[b:e] = cost_local
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+        self.bounds = balanced_row_blocks(full.tolist(), world, align=align)
+        return self.bounds
 
     def forward(self, points, attributes, adjacency, offsets, rays, start_point, depth_quantiles=None, **kw):
         return self.pipeline.trace_forward(points, attributes, adjacency, offsets, self._shard(rays),
@@ -113,5 +337,8 @@ class ShardedTracer:
         res = self.pipeline.trace_backward(points, attributes, adjacency, offsets, self._shard(rays),
                                            self._shard(start_point), rgba_local, grad_local,
                                            self._shard(depth_quantiles), depth_indices_local, depth_grad_local, **kw)
-        all_reduce_gradients(res, group=self.group)
+        if self.sparse is not None:
+            self.sparse.reduce(res)
+        else:
+            all_reduce_gradients(res, group=self.group)
         return res

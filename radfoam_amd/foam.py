@@ -192,3 +192,14 @@ def to_reference_pt_dict(foam: dict) -> dict:
         "adjacency": torch.from_numpy(foam["point_adjacency"].astype(np.int64)),
         "adjacency_offsets": torch.from_numpy(foam["point_adjacency_offsets"].astype(np.int64)),
     }
+
+
+if __name__ == "__main__":   # python -m radfoam_amd.foam N SEED: build and cache a foam's triangulation
+    import sys
+    import time
+
+    _n, _seed = int(sys.argv[1]), int(sys.argv[2])
+    _t = time.time()
+    _fm = make_synthetic_foam(_n, 0, _seed, cache_dir=default_cache_dir())
+    print(f"foam n={_n} seed={_seed}: {_fm['point_adjacency'].shape[0]} adjacency entries, "
+          f"{time.time() - _t:.1f}s, cached under {default_cache_dir()}")

@@ -58,6 +58,47 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+#: bumped by invalidate_caches(): every packed-foam / trail / ray-order cache entry made before the
+#: bump stops matching.  radfoam.Triangulation.rebuild() bumps it, because a rebuild may rewrite the
+#: adjacency buffers in place (the reference's getters are from_blob views of buffers that
+#: Triangulation::rebuild overwrites, triangulation_bindings.cpp:225-237).
+_EPOCH = [0]
+
+
+def invalidate_caches():
+    """Forget every cached packed foam / hop trail / ray order of every Pipeline.
+
+    Call it after writing to a tensor behind autograd's back -- ``param.data.add_()``, a raw pointer,
+    numpy / DLPack aliases -- i.e. whenever ``tensor._version`` does not see the write.  Ordinary
+    in-place torch ops and optimiser steps bump ``_version`` and need nothing."""
+    _EPOCH[0] += 1
+
+
+class _Uncacheable:
+    """Key of a tensor whose writes cannot be tracked (inference tensors have no version counter):
+    never equal to anything, itself included, so lookups on it always miss."""
+
+    def __eq__(self, other):
+        return False
+
+    def __ne__(self, other):
+        return True
+
+    __hash__ = None
+
+
+def _tensor_key(t):
+    """(storage address, version counter, shape, dtype, device) of a tensor, or an unmatchable key
+    when torch cannot report a version (tensors created under torch.inference_mode())."""
+    if t is None:
+        return None
+    try:
+        ver = t._version
+    except RuntimeError:
+        return _Uncacheable()
+    return (t.data_ptr(), ver, tuple(t.shape), t.dtype, t.device, _EPOCH[0])
+
+
 def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -83,8 +124,7 @@ class _FoamCache:
 
     @staticmethod
     def _key(tensors):
-        return tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device)
-                     for t in tensors)
+        return tuple(_tensor_key(t) for t in tensors)
 
     def lookup(self, tensors):
         return self.key is not None and self.key == self._key(tensors)
@@ -134,12 +174,22 @@ class Pipeline:
         #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics, 3 block cache, 4 direct row atomics
         #: (rf_launch_opts.backward_mode)
         self.backward_mode = 0
-        #: trace_forward records the face every hop went through so that a trace_backward call on
-        #: the same inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).
-        #: Costs trail_steps * 4 bytes per ray of HBM (2.1 GB for a 1080p frame at 256 steps).
-        self.record_trail = True
+        #: trace_forward records the cell every hop enters so that a trace_backward call on the same
+        #: inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).  Costs
+        #: trail_steps * 4 bytes per ray of HBM (2.1 GB for a 1080p frame at 256 steps), so:
+        #:   "auto" (default)  record only when a backward can follow: points or attributes require
+        #:                     grad (inside TraceRays.forward -- the reference's operator included --
+        #:                     the inputs still carry requires_grad); evaluation / no-grad renders
+        #:                     neither allocate nor write a trail;
+        #:   True / False      always / never (callers that drive trace_backward by hand, like
+        #:                     bench.py, set True).
+        self.record_trail = "auto"
         #: hops recorded per ray; rays that take more are re-scanned past this point
         self.trail_steps = 256
+        #: drop the trail (and its memory) once a trace_backward has replayed it; off by default because
+        #: the allocation is reused by the next trace_forward of the same shape (a training loop), and a
+        #: second backward over the same forward (tests, linearity checks) may replay it again
+        self.free_trail_after_backward = False
         self._trail = None
         #: flat ray batches (anything but [H, W, 6] images) are traced in a coherent order -- sorted by
         #: entry cell and direction (rf_build_ray_order) -- so that shuffled training batches
@@ -148,6 +198,18 @@ class Pipeline:
         #: batches smaller than this are traced as they come
         self.reorder_min_rays = 16384
         self._order = None
+
+    def invalidate(self):
+        """Forget the cached packed foam, hop trail and ray order of this Pipeline (and free the trail).
+        Needed only after writes ``tensor._version`` cannot see -- see ``invalidate_caches``."""
+        self._cache.clear()
+        self._trail = None
+        self._order = None
+
+    def _wants_trail(self, points, attributes) -> bool:
+        if self.record_trail == "auto":
+            return bool(points.requires_grad or attributes.requires_grad)
+        return bool(self.record_trail)
 
     # -- introspection (Pipeline::attribute_dim / attribute_type, pipeline.cu:768-774) ----------
     def attribute_dim(self) -> int:
@@ -292,7 +354,7 @@ class Pipeline:
     # -- hop trail -------------------------------------------------------------------------------
     @staticmethod
     def _tkey(t):
-        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device)
+        return _tensor_key(t)
 
     def _trail_key(self, foam, rays, start, quantiles, settings):
         return (tuple(self._tkey(t) for t in foam), self._tkey(rays), self._tkey(start), self._tkey(quantiles),
@@ -373,10 +435,23 @@ class Pipeline:
             depth = torch.zeros(batch + (nq,), dtype=torch.float32, device=dev)
             depth_indices = torch.zeros(batch + (nq,), dtype=torch.uint32, device=dev)
 
+        if num_rays == 0:
+            # nothing is launched, so nothing may be claimed: the foam cache is left exactly as it was
+            # (rf_trace_forward would pack the workspace even for an empty batch; skipping the call
+            # keeps "the cache key describes the workspace" independent of that)
+            self._trail = None
+            out = {"rgba": rgba}
+            if quantiles_c is not None:
+                out["depth"], out["depth_indices"] = depth, depth_indices
+            if return_contribution:
+                out["contribution"] = contribution.to(self._attr_dtype)
+            out["num_intersections"] = num_intersections
+            return out
+
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
         self._ray_order(opts, rays_c, start_c, num_rays)
         trail = None
-        if self.record_trail and num_rays > 0:
+        if self._wants_trail(points, attributes):
             trail = self._new_trail(opts, num_rays, dev)
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_forward(
@@ -494,6 +569,21 @@ class Pipeline:
         attr_grad = flat[num_points * 3:].view(num_points, a)
         ray_grad = torch.zeros_like(rays_c)
 
+        out = {
+            "points_grad": points_grad,
+            "attr_grad": attr_grad,
+            "ray_grad": ray_grad,
+            # extra key (not in the reference): the flat fp32 [points_grad | attr_grad] buffer the
+            # two views above alias, for a single gradient all-reduce (radfoam_amd/dist.py)
+            "flat_grad": flat,
+        }
+        if num_rays == 0:   # as in trace_forward: no launch, no claim on the foam cache
+            if self._attr_dtype != torch.float32:
+                out["attr_grad"] = attr_grad.to(self._attr_dtype)
+            if ray_error is not None:
+                out["point_error"] = point_error.to(self._attr_dtype)
+            return out
+
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
         self._ray_order(opts, rays_c, start_c, num_rays)
         tr = self._trail
@@ -513,15 +603,11 @@ class Pipeline:
                 _ptr(attr_grad), _ptr(point_error), C.byref(opts), _stream_ptr(dev))
         _lib.check(rc)
         self._foam_done(opts)
+        if self.free_trail_after_backward:
+            self._trail = None
 
-        out = {
-            "points_grad": points_grad,
-            "attr_grad": attr_grad if self._attr_dtype == torch.float32 else attr_grad.to(self._attr_dtype),
-            "ray_grad": ray_grad,
-            # extra key (not in the reference): the flat fp32 [points_grad | attr_grad] buffer the
-            # two views above alias, for a single gradient all-reduce (radfoam_amd/dist.py)
-            "flat_grad": flat,
-        }
+        if self._attr_dtype != torch.float32:
+            out["attr_grad"] = attr_grad.to(self._attr_dtype)
         if ray_error is not None:
             out["point_error"] = point_error.to(self._attr_dtype)
         return out

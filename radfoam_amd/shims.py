@@ -84,6 +84,10 @@ class Triangulation:
         needs_permute = not np.array_equal(perm, np.arange(len(perm)))
         self._perm = perm
         self._triangulate(np.ascontiguousarray(pts[perm]))
+        # a rebuilt triangulation invalidates whatever the tracer packed from the old adjacency, even if a
+        # caller (like the reference's from_blob getters) hands the new lists out at the old addresses
+        from .pipeline import invalidate_caches
+        invalidate_caches()
         return bool(needs_permute)
 
     def point_adjacency(self):

@@ -32,6 +32,7 @@ for name, idx in (("shuffled", rng.permutation(rays_all.shape[0])[:1_000_000]),
     start = torch.from_numpy(start_all[idx].astype(np.int64)).to(torch.uint32).to(dev)
     grad = torch.randn(rays.shape[0], 4, device=dev)
     pipe = radfoam.create_pipeline(d, torch.float32)
+    pipe.record_trail = True   # backward is driven by hand on plain tensors
     ts = []
     for it in range(5):
         pipe._cache.invalidate_geometry()

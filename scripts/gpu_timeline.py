@@ -20,6 +20,7 @@ adjacency = torch.from_numpy(fm["point_adjacency"]).to(dev)
 offsets = torch.from_numpy(fm["point_adjacency_offsets"]).to(dev)
 start = torch.full(rays.shape[:-1], start_idx, dtype=torch.int64).to(torch.uint32).to(dev)
 pipe = radfoam.create_pipeline(2, torch.float32)
+pipe.record_trail = True   # backward is driven by hand on plain tensors
 nblk = ((1920 + 15) // 16) * ((1080 + 15) // 16)
 for _ in range(2):
     pipe.walk_statistics(points, attributes, adjacency, offsets, rays, start, extra_slots=4 * nblk)

@@ -21,6 +21,7 @@ offsets = torch.from_numpy(fm["point_adjacency_offsets"]).to(dev)
 start = torch.full(rays.shape[:-1], start_idx, dtype=torch.int64).to(torch.uint32).to(dev)
 grad = torch.randn(rays.shape[:-1] + (4,), generator=torch.Generator().manual_seed(1234)).to(dev)
 pipe = radfoam.create_pipeline(2, torch.float32)
+pipe.record_trail = True   # backward is driven by hand on plain tensors
 nblk = ((1920 + 15) // 16) * ((1080 + 15) // 16)
 stats = torch.zeros(8 + 4 * nblk, dtype=torch.int64, device=dev)
 orig = pipe._launch_opts

@@ -66,7 +66,7 @@ def _worker(rank, world, port, d, results):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         fm = foam.make_synthetic_foam(1500, d, 4)
-        cam, rays_np, start = H.camera_setup(fm, 20, 13)   # 13 rows: uneven split 7 + 6
+        cam, rays_np, start = H.camera_setup(fm, 20, 13)   # 13 rows: uneven split 7 + 6 (or 5 + 4 + 4)
         t = torch.from_numpy
         p, a, adj, off = t(fm["points"]), t(fm["attributes"]), t(fm["point_adjacency"]), t(fm["point_adjacency_offsets"])
         rays = t(rays_np)
@@ -74,12 +74,51 @@ def _worker(rank, world, port, d, results):
         g = torch.from_numpy(np.random.default_rng(0).normal(size=rays.shape[:-1] + (4,)).astype(np.float32))
 
         pipe = OraclePipeline(d)
-        tracer = rdist.ShardedTracer(pipe)
+        tracer = rdist.ShardedTracer(pipe, exchange="dense")
         fwd = tracer.forward(p, a, adj, off, rays, starts)
         b, e = rdist.row_block(13, rank, world)
         assert fwd["rgba"].shape == (e - b, 20, 4)
         image = rdist.gather_rows(fwd["rgba"], 13)
         bwd = tracer.backward(p, a, adj, off, rays, starts, fwd["rgba"], rdist.shard_rows(g, rank, world))
+
+        # the sparse exchange gives the dense all-reduce's sums: exactly for two ranks (one addition per
+        # element, commutative), and the same bits on every rank for any world size
+        sparse = rdist.ShardedTracer(pipe, exchange="sparse")
+        sparse.sparse.dense_fraction = 10.0          # this toy foam is touched almost everywhere: no fallback
+        bwd_s = sparse.backward(p, a, adj, off, rays, starts, fwd["rgba"], rdist.shard_rows(g, rank, world))
+        assert sparse.sparse.last_counts is not None and len(sparse.sparse.last_counts) == world
+        assert 0 < max(sparse.sparse.last_counts) <= p.shape[0]
+        if world == 2:
+            assert torch.equal(bwd_s["flat_grad"], bwd["flat_grad"])
+        else:
+            assert torch.allclose(bwd_s["flat_grad"], bwd["flat_grad"], rtol=1e-5, atol=1e-6)
+        same = [torch.empty_like(bwd_s["flat_grad"]) for _ in range(world)]
+        dist.all_gather(same, bwd_s["flat_grad"])
+        assert all(torch.equal(same[0], x) for x in same[1:]), "ranks disagree on the summed gradients"
+        # a second call reuses the buffers; a tiny initial capacity exercises the grow-and-retry path
+        small = rdist.SparseGradExchange(dense_fraction=10.0)
+        small._buffers(3, world, small._pitch(pipe.attribute_dim()), p)
+        res2 = pipe.trace_backward(p, a, adj, off, sparse._shard(rays), sparse._shard(starts), fwd["rgba"],
+                                   rdist.shard_rows(g, rank, world))
+        small.reduce(res2)
+        assert torch.equal(res2["flat_grad"], bwd_s["flat_grad"])
+        # fallback to the dense all-reduce when the lists are not sparse
+        dense_fb = rdist.SparseGradExchange(dense_fraction=0.0)
+        res3 = pipe.trace_backward(p, a, adj, off, sparse._shard(rays), sparse._shard(starts), fwd["rgba"],
+                                   rdist.shard_rows(g, rank, world))
+        dense_fb.reduce(res3)
+        assert dense_fb.last_counts is None and torch.allclose(res3["flat_grad"], bwd["flat_grad"], rtol=1e-5, atol=1e-6)
+
+        # cost-balanced row blocks: same image, same gradients, boundaries agreed by all ranks
+        bounds = sparse.rebalance(fwd["num_intersections"], 13, align=1)
+        assert bounds[0] == 0 and bounds[-1] == 13 and all(x < y for x, y in zip(bounds, bounds[1:]))
+        fwd_b = sparse.forward(p, a, adj, off, rays, starts)
+        assert fwd_b["rgba"].shape[0] == bounds[rank + 1] - bounds[rank]
+        image_b = rdist.gather_rows(fwd_b["rgba"], 13, bounds=bounds)
+        assert torch.equal(image_b, image)
+        bwd_b = sparse.backward(p, a, adj, off, rays, starts, fwd_b["rgba"],
+                                rdist.shard_rows(g, rank, world, bounds=bounds))
+        assert torch.allclose(bwd_b["flat_grad"], bwd["flat_grad"], rtol=1e-5, atol=1e-6)
 
         full_f = pipe.trace_forward(p, a, adj, off, rays, starts)
         full_b = pipe.trace_backward(p, a, adj, off, rays, starts, full_f["rgba"], g)
@@ -95,9 +134,8 @@ def _worker(rank, world, port, d, results):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("d", [0, 2])
-def test_row_sharded_forward_backward_gloo(d):
-    world = 2
+@pytest.mark.parametrize("d,world", [(0, 2), (2, 2), (1, 3)])
+def test_row_sharded_forward_backward_gloo(d, world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     results = ctx.Manager().dict()
@@ -111,7 +149,7 @@ def test_row_sharded_forward_backward_gloo(d):
             pr.kill()
             pytest.fail("distributed worker hung")
         assert pr.exitcode == 0
-    assert dict(results) == {0: 1, 1: 1}
+    assert dict(results) == {r: 1 for r in range(world)}
 
 
 def test_row_blocks_partition():
@@ -125,3 +163,28 @@ def test_row_blocks_partition():
         assert max(sizes) - min(sizes) <= 1
     x = torch.arange(26).reshape(13, 2)
     assert torch.equal(torch.cat([rdist.shard_rows(x, r, 2) for r in range(2)]), x)
+
+
+def test_balanced_row_blocks():
+    import numpy as np
+    from radfoam_amd import dist as rdist
+
+    rows = np.arange(1080)
+    cost = 100.0 + 60.0 * np.abs(rows - 540) / 540.0          # frame edges cost more than the centre
+    for world in (2, 4, 8):
+        even = [cost[slice(*rdist.row_block(1080, r, world))].sum() for r in range(world)]
+        b = rdist.balanced_row_blocks(cost, world, align=8)
+        assert b[0] == 0 and b[-1] == 1080 and len(b) == world + 1
+        assert all(x % 8 == 0 for x in b[:-1]) and all(x < y for x, y in zip(b, b[1:]))
+        bal = [cost[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(bal) / np.mean(bal) <= 1.07                 # within one 8-row band per boundary
+        if world == 8:                                        # where the even split is visibly unbalanced
+            assert max(even) / np.mean(even) > 1.15 and max(bal) / np.mean(bal) < max(even) / np.mean(even)
+    # degenerate inputs: zero cost -> even bands; fewer bands than ranks -> plain even split
+    assert rdist.balanced_row_blocks([0.0] * 64, 4, align=8) == [0, 16, 32, 48, 64]
+    assert rdist.balanced_row_blocks([1.0] * 5, 8, align=8) == [0, 1, 2, 3, 4, 5, 5, 5, 5]
+    # all the cost in one row: every block still gets at least one band
+    spike = [0.0] * 64
+    spike[3] = 1.0
+    b = rdist.balanced_row_blocks(spike, 4, align=8)
+    assert b[0] == 0 and b[-1] == 64 and all(x < y for x, y in zip(b, b[1:]))

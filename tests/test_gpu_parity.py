@@ -20,9 +20,15 @@ DEV = "cuda:0"
 
 
 def _pipeline(d, dtype=torch.float32):
+    """Pipeline with the hop trail always recorded: these tests drive trace_forward / trace_backward by
+    hand on plain tensors, where the default ("auto": record when points or attributes require grad)
+    would leave every backward on the re-walk kernel.  The default itself is covered by
+    test_trail_is_recorded_only_when_a_backward_can_follow."""
     import radfoam
 
-    return radfoam.create_pipeline(d, dtype)
+    pipe = radfoam.create_pipeline(d, dtype)
+    pipe.record_trail = True
+    return pipe
 
 
 def _run_forward(pipe, fm, rays, start, attr_dtype=None, **kw):
@@ -281,8 +287,10 @@ def test_geometry_only_repack_after_an_optimiser_step(foam_factory, d):
     res = pipe.trace_backward(p, a, adj, off, r, s, out["rgba"], g)
     refb = O.trace_backward(d, pts2, att2, fm["point_adjacency"], fm["point_adjacency_offsets"], rays, start,
                             ref["rgba"], g.cpu().numpy())
-    H.grad_close(res["points_grad"].cpu().numpy(), refb["points_grad"])
-    H.grad_close(res["attr_grad"].cpu().numpy(), refb["attr_grad"])
+    for key in ("points_grad", "attr_grad"):
+        ok, rel, worst = H.grad_close(res[key].cpu().numpy(), refb[key])
+        assert ok and rel < 1e-5, (key, rel, worst)
+        assert np.abs(refb[key]).max() > 0
     # a new adjacency tensor (a rebuilt triangulation) is packed from scratch
     assert pipe._launch_opts(p, a, adj.clone(), off, r.shape).foam_prepared == 0
 
@@ -325,10 +333,13 @@ def _full_size_cases():
     only when its cached triangulation travelled with the repository."""
     import os
     from radfoam_amd import foam
-    cases = [pytest.param(500_000, 1, id="config2-500k")]
-    if os.path.exists(os.path.join(foam.default_cache_dir(), "foam_n2000000_s5.npz")):
-        cases.append(pytest.param(2_000_000, 5, id="north-star-2M"))
-    return cases
+    have_2m = os.path.exists(os.path.join(foam.default_cache_dir(), "foam_n2000000_s5.npz"))
+    return [
+        pytest.param(500_000, 1, id="config2-500k"),
+        pytest.param(2_000_000, 5, id="north-star-2M", marks=pytest.mark.skipif(
+            not have_2m, reason="the cached triangulation .foam_cache/foam_n2000000_s5.npz is not here "
+                                "(Qhull on 2M points takes minutes; python -m radfoam_amd.foam 2000000 5 builds it)")),
+    ]
 
 
 @pytest.mark.parametrize("n_points,seed", _full_size_cases())
@@ -376,6 +387,143 @@ def test_full_size_frame_properties(n_points, seed):
         rel = float((x - y).double().norm() / y.double().norm())
         assert rel < 1e-5, rel
     assert torch.isfinite(pg1).all() and torch.isfinite(ag1).all() and float(ag1.abs().max()) > 0
+
+
+def test_full_frame_gradients_against_the_oracle():
+    """BASELINE config 2 at full size (500k points, 1080x1920, SH 2): the gradients of the WHOLE frame
+    against the oracle's -- every ray, the block cache under its real load (evictions, bypasses, the
+    re-walk launch for rays longer than the trail) -- not only the 5k-point cases above."""
+    from radfoam_amd import foam
+    d = 2
+    fm = foam.make_synthetic_foam(500_000, d, 1, cache_dir=foam.default_cache_dir())
+    cam, rays, start = H.camera_setup(fm, 1920, 1080)
+    gen = np.random.default_rng(17)
+    g = gen.normal(size=rays.shape[:-1] + (4,)).astype(np.float32)
+    args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"], pad=32)
+    ref_f = O.trace_forward(*args, rays, start, diff=diff)
+    ref_b = O.trace_backward(*args, rays, start, ref_f["rgba"], g, diff=diff)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    r = torch.from_numpy(rays).to(DEV)
+    s = torch.full(r.shape[:-1], int(start), dtype=torch.int64).to(torch.uint32).to(DEV)
+    tg = torch.from_numpy(g).to(DEV)
+    for mode, trail_steps in ((0, 256), (0, 64), (4, 256)):   # default; short trail -> replay + re-walk; direct rows
+        pipe = _pipeline(d)
+        pipe.backward_mode = mode
+        pipe.trail_steps = trail_steps
+        out = pipe.trace_forward(p, a, adj, off, r, s)
+        np.testing.assert_array_equal(out["rgba"].cpu().numpy().view(np.uint32), ref_f["rgba"].view(np.uint32))
+        np.testing.assert_array_equal(out["num_intersections"].cpu().numpy().view(np.uint32)[..., 0],
+                                      ref_f["num_intersections"].reshape(1080, 1920))
+        res = pipe.trace_backward(p, a, adj, off, r, s, out["rgba"], tg)
+        for key in ("points_grad", "attr_grad"):
+            ok, rel, worst = H.grad_close(res[key].cpu().numpy(), ref_b[key])
+            assert ok and rel < 1e-5, (mode, trail_steps, key, rel, worst)
+            assert np.abs(ref_b[key]).max() > 0
+        del pipe, out, res
+        torch.cuda.empty_cache()
+
+
+def test_empty_batch_does_not_poison_the_foam_cache(foam_factory):
+    """An empty call on fresh tensors packs nothing and must not leave a cache entry that a later
+    non-empty call on the same tensors would trust."""
+    d = 1
+    fm = foam_factory(5000, d, 91)
+    cam, rays, start = H.camera_setup(fm, 40, 32)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    r = torch.from_numpy(rays).to(DEV)
+    s = torch.full(r.shape[:-1], int(start), dtype=torch.int64).to(torch.uint32).to(DEV)
+    ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                          fm["point_adjacency_offsets"], rays, start)
+    g = np.random.default_rng(2).normal(size=rays.shape[:-1] + (4,)).astype(np.float32)
+    refb = O.trace_backward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                            fm["point_adjacency_offsets"], rays, start, ref["rgba"], g)
+    e_r = torch.zeros((0, 6), device=DEV)
+    e_s = torch.zeros((0,), dtype=torch.uint32, device=DEV)
+    for first in ("forward", "backward", "statistics"):
+        pipe = _pipeline(d)
+        # poison: whatever workspace the allocator hands out next holds garbage
+        junk = torch.full((64 << 20,), 0x7F, dtype=torch.uint8, device=DEV)
+        del junk
+        if first == "forward":
+            out0 = pipe.trace_forward(p, a, adj, off, e_r, e_s, return_contribution=True)
+            assert out0["rgba"].shape == (0, 4) and out0["contribution"].shape == (5000, 1)
+        elif first == "backward":
+            b0 = pipe.trace_backward(p, a, adj, off, e_r, e_s, torch.zeros((0, 4), device=DEV),
+                                     torch.zeros((0, 4), device=DEV))
+            assert b0["points_grad"].shape == (5000, 3) and float(b0["attr_grad"].abs().max()) == 0.0
+        else:
+            st = pipe.walk_statistics(p, a, adj, off, e_r, e_s)
+            assert st["cells_scanned"] == 0
+        out = pipe.trace_forward(p, a, adj, off, r, s)
+        np.testing.assert_array_equal(out["rgba"].cpu().numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+        res = pipe.trace_backward(p, a, adj, off, r, s, out["rgba"], torch.from_numpy(g).to(DEV))
+        for key in ("points_grad", "attr_grad"):
+            ok, rel, worst = H.grad_close(res[key].cpu().numpy(), refb[key])
+            assert ok and rel < 1e-5, (first, key, rel, worst)
+
+
+def test_trail_is_recorded_only_when_a_backward_can_follow(foam_factory):
+    """Default record_trail="auto": no trail for plain (evaluation) tensors; a trail when points or
+    attributes require grad -- which is what TraceRays.forward sees, the reference's included."""
+    import radfoam
+    from radfoam_amd.render import TraceRays
+
+    d = 0
+    fm = foam_factory(5000, d, 92)
+    cam, rays, start = H.camera_setup(fm, 32, 32)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    r = torch.from_numpy(rays).to(DEV)
+    s = torch.full(r.shape[:-1], int(start), dtype=torch.int64).to(torch.uint32).to(DEV)
+    pipe = radfoam.create_pipeline(d)
+    assert pipe.record_trail == "auto"
+    with torch.no_grad():
+        ev = pipe.trace_forward(p, a, adj, off, r, s)
+    assert pipe._trail is None
+    pg, ag = p.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    rgba, _, _, _, _ = TraceRays.apply(pipe, pg, ag, adj, off, r, s, None, False)
+    assert pipe._trail is not None and torch.equal(rgba.detach(), ev["rgba"])
+    rgba.sum().backward()
+    assert pg.grad is not None and float(ag.grad.abs().max()) > 0
+    # inference tensors have no version counter: traced uncached instead of failing
+    with torch.inference_mode():
+        pi, ai = p.clone(), a.clone()
+        out = pipe.trace_forward(pi, ai, adj, off, r, s)
+        out2 = pipe.trace_forward(pi, ai, adj, off, r, s)
+    assert torch.equal(out["rgba"], ev["rgba"]) and torch.equal(out2["rgba"], ev["rgba"])
+    assert pipe._cache.key is None or not pipe._cache.lookup((pi, ai, adj, off, None))
+
+
+def test_invalidate_after_a_write_autograd_cannot_see(foam_factory):
+    """`.data` writes do not bump _version (the documented hazard of the foam cache): the stale
+    result is what an uninformed cache gives, Pipeline.invalidate() / radfoam.invalidate_caches()
+    are the documented remedies."""
+    import radfoam
+
+    d = 0
+    fm = foam_factory(5000, d, 93)
+    cam, rays, start = H.camera_setup(fm, 32, 32)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    r = torch.from_numpy(rays).to(DEV)
+    s = torch.full(r.shape[:-1], int(start), dtype=torch.int64).to(torch.uint32).to(DEV)
+    fm2 = dict(fm)
+    fm2["attributes"] = fm["attributes"].copy()
+    fm2["attributes"][:, -1] *= 0.25
+    ref2 = O.trace_forward(d, fm2["points"], fm2["attributes"], fm2["point_adjacency"],
+                           fm2["point_adjacency_offsets"], rays, start)
+    for remedy in ("pipeline", "global"):
+        pa = a.clone()
+        pipe = _pipeline(d)
+        pipe.trace_forward(p, pa, adj, off, r, s)
+        v = pa._version
+        pa.data[:, -1] *= 0.25
+        assert pa._version == v
+        if remedy == "pipeline":
+            pipe.invalidate()
+        else:
+            radfoam.invalidate_caches()
+        out = pipe.trace_forward(p, pa, adj, off, r, s)
+        np.testing.assert_array_equal(out["rgba"].cpu().numpy().view(np.uint32), ref2["rgba"].view(np.uint32))
 
 
 import glob as _glob
@@ -443,7 +591,8 @@ def test_shuffled_batch_is_traced_in_a_coherent_order(foam_factory):
     (f1, b1), (f0, b0) = outs
     for k in ("rgba", "depth", "depth_indices", "num_intersections"):
         assert torch.equal(f1[k], f0[k]), k
-    H.grad_close(f1["contribution"].cpu().numpy(), f0["contribution"].cpu().numpy())
+    ok, rel, worst = H.grad_close(f1["contribution"].cpu().numpy(), f0["contribution"].cpu().numpy())
+    assert ok and rel < 1e-5, ("contribution", rel, worst)
     for k in ("points_grad", "attr_grad"):
         ok, rel, worst = H.grad_close(b1[k].cpu().numpy(), b0[k].cpu().numpy())
         assert ok and rel < 1e-5, (k, rel, worst)
