@@ -178,6 +178,19 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
                        const rf_camera *camera, const uint32_t *start_point_index,
                        uint32_t *ray_rgba, const rf_launch_opts *opts, void *stream);
 
+/* Number of adjacency entries of a foam = point_adjacency_offsets[num_points], read back from the device (one
+ * 4-byte copy on `stream`, which is synchronised).  Pipeline::trace_benchmark (src/tracing/pipeline.h:117-126)
+ * receives no adjacency size, while rf_workspace_bytes() / rf_trace_benchmark() need it on the host: a
+ * reference-side binding asks here (once per scene: the value only changes with the triangulation). */
+int rf_adjacency_size(uint32_t num_points, const uint32_t *point_adjacency_offsets,
+                      uint32_t *point_adjacency_size /* HOST */, void *stream);
+
+/* Rounds an fp32 accumulator into a buffer of the pipeline's attribute type: dst[i] = (attr_type) src[i] for
+ * i < count (fp16: round to nearest even; fp32: a copy).  The reference's `point_contribution`,
+ * `attribute_grad` and `point_error` buffers have the attribute type (pipeline.h:62-100) while this library
+ * accumulates them in fp32 for both types; an fp16 binding accumulates into fp32 scratch and finishes with this. */
+int rf_cast_accumulator(const float *src, size_t count, int attr_type, void *dst, void *stream);
+
 /* The part of rf_prepare_foam that depends on points / attributes: rewrites cell records, fp16 face
  * offsets and SH rows of a workspace whose adjacency-derived part (padded offsets, links) was
  * packed by rf_prepare_foam for the same point_adjacency / offsets (without adjacent_diff). */

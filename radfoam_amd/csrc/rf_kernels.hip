@@ -836,7 +836,7 @@ __device__ __forceinline__ bool backward_segment(const BwdParams &p, BwdRay &R, 
     float dLr = R.gr * w, dLg = R.gg * w, dLb = R.gb * w;
     float den = R.T * ((1.0f - alpha) + 1e-6f);
     float rr, rg, rb;
-    div3(R.outr - R.Cr, R.outg - R.Cg, R.outb - R.Cb, den, rr, rg, rb);
+    div3_guarded(R.outr - R.Cr, R.outg - R.Cg, R.outb - R.Cb, den, rr, rg, rb);
     float dfr = r - rr;
     float dfg = g - rg;
     float dfb = b - rb;

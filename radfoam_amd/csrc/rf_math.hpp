@@ -126,18 +126,8 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float (&sh)[
 // (nx, ny, nz) / den with one shared reciprocal: the instruction sequence hipcc expands each IEEE
 // fp32 divide into (v_rcp_f32, one Newton step on the reciprocal, two residual corrections of the
 // quotient) without v_div_scale / v_div_fmas / v_div_fixup, which only act when an operand or the
-// quotient is subnormal, huge, zero, infinite or NaN.  Bit-identical to three '/' otherwise; a
-// denominator outside the range where that holds takes the plain divides.
+// quotient is subnormal, huge, zero, infinite or NaN.  Bit-identical to three '/' otherwise.
 __device__ __forceinline__ void div3(float nx, float ny, float nz, float den, float &qx, float &qy, float &qz) {
-    // |den| outside [2^-60, 2^60] (or zero, subnormal, inf, NaN): the scaling steps that sequence
-    // leaves out would act, so take the IEEE divide itself.  Reached e.g. with weight_threshold = 0,
-    // where the transmittance in the compositing denominators decays into the subnormal range.
-    if (((f2bits(den) >> 23) & 0xFFu) - 67u > 120u) {
-        qx = nx / den;
-        qy = ny / den;
-        qz = nz / den;
-        return;
-    }
     float y = __builtin_amdgcn_rcpf(den);
     float e = fma_(-den, y, 1.0f);
     y = fma_(e, y, y);
@@ -145,6 +135,18 @@ __device__ __forceinline__ void div3(float nx, float ny, float nz, float den, fl
     q = nx * y; r = fma_(-den, q, nx); q = fma_(r, y, q); r = fma_(-den, q, nx); qx = fma_(r, y, q);
     q = ny * y; r = fma_(-den, q, ny); q = fma_(r, y, q); r = fma_(-den, q, ny); qy = fma_(r, y, q);
     q = nz * y; r = fma_(-den, q, nz); q = fma_(r, y, q); r = fma_(-den, q, nz); qz = fma_(r, y, q);
+}
+
+// div3 for a denominator that can leave the range where the short sequence is exact: numerators and
+// denominator are first scaled by the same power of two (exact; what v_div_scale does for the IEEE divide) so
+// that |den| is back in the normal range -- the quotients are unchanged.  Used for the compositing denominator
+// T * (1 - alpha + 1e-6) of the backward pass, whose transmittance T decays into the subnormal range when a
+// caller sets weight_threshold = 0; the bisector denominators (dp^2 of a face the ray crosses) never do.
+// Branch-free: three selects and four v_ldexp_f32.
+__device__ __forceinline__ void div3_guarded(float nx, float ny, float nz, float den, float &qx, float &qy, float &qz) {
+    const uint32_t ex = (f2bits(den) >> 23) & 0xFFu;
+    const int sc = ex < 67u ? 64 : (ex > 187u ? -64 : 0);
+    div3(__builtin_ldexpf(nx, sc), __builtin_ldexpf(ny, sc), __builtin_ldexpf(nz, sc), __builtin_ldexpf(den, sc), qx, qy, qz);
 }
 
 // d(t)/d(primal) of the ray/bisector(primal,opposite) hit; reference: cell_intersection_grad,

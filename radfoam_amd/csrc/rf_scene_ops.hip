@@ -175,6 +175,14 @@ __global__ __launch_bounds__(256) void farthest_neighbor_kernel(const float *__r
     cell_radius[i] = sum / (float)(e - b);
 }
 
+// fp32 accumulator -> attribute type, one scalar per thread (rf_cast_accumulator)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_accumulator_kernel(const float *__restrict__ src, size_t count,
+                                                               T *__restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = to_attr<T>(src[i]);
+}
+
 }  // namespace rf
 
 using namespace rf;
@@ -248,6 +256,35 @@ int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_
                        static_cast<hipStream_t>(stream), points, point_adjacency, point_adjacency_offsets,
                        num_points, indices, cell_radius);
     return check_launch("rf_farthest_neighbor");
+}
+
+
+int rf_adjacency_size(uint32_t num_points, const uint32_t *point_adjacency_offsets, uint32_t *point_adjacency_size,
+                      void *stream) {
+    g_err[0] = 0;
+    if (!point_adjacency_offsets || !point_adjacency_size)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_adjacency_size: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(point_adjacency_size, point_adjacency_offsets + num_points, sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(RF_ERR_LAUNCH, "rf_adjacency_size: %s", hipGetErrorString(e));
+    return RF_OK;
+}
+
+int rf_cast_accumulator(const float *src, size_t count, int attr_type, void *dst, void *stream) {
+    g_err[0] = 0;
+    if (count == 0) return RF_OK;
+    if (!src || !dst) return fail(RF_ERR_INVALID_ARGUMENT, "rf_cast_accumulator: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    if (attr_type == RF_ATTR_FLOAT16)
+        hipLaunchKernelGGL(cast_accumulator_kernel<uint16_t>, grid, block, 0, s, src, count, static_cast<uint16_t *>(dst));
+    else if (attr_type == RF_ATTR_FLOAT32)
+        hipLaunchKernelGGL(cast_accumulator_kernel<float>, grid, block, 0, s, src, count, static_cast<float *>(dst));
+    else
+        return fail(RF_ERR_INVALID_ARGUMENT, "Unsupported attribute type");
+    return check_launch("rf_cast_accumulator");
 }
 
 }  // extern "C"

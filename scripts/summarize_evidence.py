@@ -5,16 +5,17 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 d = sys.argv[1]
 
 
 def short(name):
-    n = name.split("rf::")[-1].split("(")[0]
-    base = n.split("<")[0]
+    m = re.search(r"rf::(\w+)(<[^>]*>)?", name)
+    base, targs = m.group(1), (m.group(2) or "")
     # the statistics instance of the forward kernel (<..., QUANT=true, STATS=true>) is not a bench kernel
-    if base == "forward_kernel" and n.rstrip(">").endswith("true, true"):
+    if base == "forward_kernel" and targs.rstrip(">").endswith("true, true"):
         base = "forward_kernel[stats]"
     return base
 
@@ -52,9 +53,10 @@ for pm in sorted(glob.glob(os.path.join(d, "pmc_*"))):
             e = out[k]
             v = e.get("SQ_ACTIVE_INST_VALU")
             g = e.get("GRBM_GUI_ACTIVE")
+            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (8 GRBM instances): per-XCD cycles = g / 8
             print(f"[{w}] {k}: dur {e['duration_ns'] / 1e6:.3f} ms"
-                  + (f", VALU issue {4 * v / (1024 * g):.3f}, VALU insts {e.get('SQ_INSTS_VALU', 0):.4g}, "
-                     f"eff clock {g / e['duration_ns']:.2f} GHz" if v and g else "")
+                  + (f", VALU issue {4 * v / (1024 * g / 8):.3f}, VALU insts {e.get('SQ_INSTS_VALU', 0):.4g}, "
+                     f"eff clock {g / 8 / e['duration_ns']:.2f} GHz" if v and g else "")
                   + (f", HBM {e['hbm_bytes'] / 1e9:.2f} GB (raw {e['hbm_bytes_raw'] / 1e9:.2f})" if "hbm_bytes" in e else ""))
 
 for f in sorted(glob.glob(os.path.join(d, "bench*.json"))):

@@ -182,6 +182,44 @@ def test_backward_parity(foam_factory, d, image, quantiles, with_error, mode, tr
         assert np.abs(ref[key]).max() > 0
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_backward_with_zero_weight_threshold(foam_factory, mode):
+    """weight_threshold = 0 on an opaque foam: the transmittance in the compositing denominators decays
+    through the subnormal range to 0, where the short divide sequence alone is not IEEE (ADVICE r1);
+    gradients must still match the oracle's (plain '/')."""
+    d = 1
+    fm = dict(foam_factory(5000, d, 26))
+    fm["attributes"] = fm["attributes"].copy()
+    fm["attributes"][:, -1] *= 60.0
+    cam, rays, start = H.camera_setup(fm, 48, 40)
+    starts = np.full(rays.shape[:-1], start, dtype=np.uint32)
+    g = np.random.default_rng(3).normal(size=rays.shape[:-1] + (4,)).astype(np.float32)
+    args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    fwd = O.trace_forward(*args, rays, starts, weight_threshold=0.0)
+    ref = O.trace_backward(*args, rays, starts, fwd["rgba"], g, weight_threshold=0.0, num_threads=1)
+    assert fwd["rgba"][..., 3].max() == 1.0          # saturated: T reached exactly 0 somewhere
+    pipe = _pipeline(d)
+    pipe.backward_mode = mode
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    t = lambda x: torch.from_numpy(x).to(DEV)
+    f = pipe.trace_forward(p, a, adj, off, t(rays), t(starts), weight_threshold=0.0)
+    np.testing.assert_array_equal(f["rgba"].cpu().numpy().view(np.uint32), fwd["rgba"].view(np.uint32))
+    np.testing.assert_array_equal(f["num_intersections"].cpu().numpy().view(np.uint32).reshape(-1),
+                                  fwd["num_intersections"].reshape(-1))
+    out = pipe.trace_backward(p, a, adj, off, t(rays), t(starts), f["rgba"], t(g), weight_threshold=0.0)
+    for key in ("points_grad", "attr_grad"):
+        got, want = out[key].cpu().numpy(), ref[key]
+        # the reference's own arithmetic yields inf / NaN here (0 * inf, inf - inf in the saturated tail; zeroed
+        # afterwards by render.py:98-99): they must sit in (nearly) the same places -- sums that overflow in a
+        # different order may differ in a handful -- and everything finite in both must agree
+        fin_w, fin_g = np.isfinite(want), np.isfinite(got)
+        assert (fin_w != fin_g).mean() < 2e-3, (key, (fin_w != fin_g).mean())
+        assert 0.5 < fin_w.mean() < 1.0
+        both = fin_w & fin_g
+        ok, rel, worst = H.grad_close(np.where(both, got, 0.0), np.where(both, want, 0.0))
+        assert ok and rel < 1e-5, (key, rel, worst)
+
+
 def test_autograd_operator_matches_oracle(foam_factory):
     """TraceRays (radfoam_amd/render.py) end to end, incl. the non-finite scrub."""
     from radfoam_amd.render import TraceRays
