@@ -198,9 +198,11 @@ __device__ __forceinline__ void face_hit(float ox, float oy, float oz, float Px,
                                          float Ox, float Oy, float Oz, float dx, float dy, float dz,
                                          float &dp, float &t) {
     dp = dot3(ox, oy, oz, dx, dy, dz);
-    float vx = fma_(ox, 0.5f, Px) - Ox;
-    float vy = fma_(oy, 0.5f, Py) - Oy;
-    float vz = fma_(oz, 0.5f, Pz) - Oz;
+    // v = (P - O) + o/2: the cell-minus-origin term is the same for every face of the cell, so the scan forms
+    // it once per step (canonical order; the reference writes (P + o/2) - O)
+    float vx = fma_(ox, 0.5f, Px - Ox);
+    float vy = fma_(oy, 0.5f, Py - Oy);
+    float vz = fma_(oz, 0.5f, Pz - Oz);
     t = dot3(vx, vy, vz, ox, oy, oz) / dp;
 }
 
@@ -251,8 +253,8 @@ __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t c
     r.t1 = __builtin_inff();
     constexpr int kUnset = -0x40000000;
     int rel = kUnset;
-    const v2f P2x = {Px, Px}, P2y = {Py, Py}, P2z = {Pz, Pz};
-    const v2f O2x = {Ox, Ox}, O2y = {Oy, Oy}, O2z = {Oz, Oz};
+    const float cx = Px - Ox, cy = Py - Oy, cz = Pz - Oz;   // once per cell, not per face
+    const v2f C2x = {cx, cx}, C2y = {cy, cy}, C2z = {cz, cz};
     const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
     const v2f half2 = {0.5f, 0.5f};
     const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
@@ -270,10 +272,10 @@ __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t c
             const v2f oz = {half_lo(wz), half_hi(wz)};
             // dp = fma(ox,dx, fma(oy,dy, oz*dz))
             const v2f dpp = fma2(ox, d2x, fma2(oy, d2y, oz * d2z));
-            // v = (P + o/2) - O ; num = fma(vx,ox, fma(vy,oy, vz*oz))
-            const v2f vx = fma2(ox, half2, P2x) - O2x;
-            const v2f vy = fma2(oy, half2, P2y) - O2y;
-            const v2f vz = fma2(oz, half2, P2z) - O2z;
+            // v = (P - O) + o/2 ; num = fma(vx,ox, fma(vy,oy, vz*oz))
+            const v2f vx = fma2(ox, half2, C2x);
+            const v2f vy = fma2(oy, half2, C2y);
+            const v2f vz = fma2(oz, half2, C2z);
             const v2f num = fma2(vx, ox, fma2(vy, oy, vz * oz));
             const v2f q = div2(num, dpp);
             dp[2 * h] = dpp.x;
@@ -1165,6 +1167,12 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 #ifndef RF_DTABLE_EPOCH
 #define RF_DTABLE_EPOCH 4
 #endif
+#ifndef RF_STAGE_LANES_D3
+#define RF_STAGE_LANES_D3 32
+#endif
+#ifndef RF_DIRECT_WAVES_D3
+#define RF_DIRECT_WAVES_D3 3
+#endif
 constexpr int kCacheProbes = RF_CACHE_PROBES;
 constexpr uint32_t kEpoch = RF_CACHE_EPOCH;
 
@@ -1449,15 +1457,19 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
 // a block-level table: 768 cells x one double, same-cell lanes pre-merged by DPP, entries untouched
 // for 4 steps flushed as single atomics (13.1 -> 8.1 ms).
 template <int DEG, bool HALF, bool QUANT>
-__global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : 3)) void backward_replay_direct_kernel(BwdParams p) {
+__global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void backward_replay_direct_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
     constexpr int A = 1 + 3 * NB;
     constexpr int NC = 3 * NB;
     constexpr int SHP = (NC + 3) & ~3;             // staged floats per lane, float4-padded
     constexpr int PITCH = SHP;
-    __shared__ __attribute__((aligned(16))) float s_stage[kBlock * PITCH];
+    // Lanes of a wave staged at a time.  The 48-float rows of SH degree 3 staged for all 64 lanes are 48 KB per
+    // block: with the density table two blocks fit a CU (2 waves/SIMD, and every cell gather of a sparse batch
+    // is its own cache miss to hide).  Staging one half-wave after the other halves that (4 blocks per CU).
+    constexpr int STAGE_LANES = RF_STAGE_LANES_D3 == 32 && DEG == 3 ? 32 : 64;
+    __shared__ __attribute__((aligned(16))) float s_stage[(kBlock / 64) * STAGE_LANES * PITCH];
     const uint32_t lane = threadIdx.x & 63u;
-    float *stage = s_stage + (threadIdx.x & ~63u) * PITCH;   // this wave's 64 slots
+    float *stage = s_stage + (threadIdx.x >> 6) * (STAGE_LANES * PITCH);   // this wave's slots
     // density gradients (one per segment: the bulk of the requests) are first summed per cell in a
     // small block-level table of doubles; entries untouched for an epoch go out as single atomics
     constexpr int DROWS = RF_DTABLE_ROWS;
@@ -1520,43 +1532,50 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : 3)) void backward_replay_di
             }
             // colour rows: stage lane-major, emit column-major (two rows per pass, a lane per column)
             const bool lit = G.has && G.row;
-            unsigned long long todo = ballot(lit);
-            if (todo != 0ull) {
-                if (lit) {
-                    float4 *dst4 = reinterpret_cast<float4 *>(stage + lane * PITCH);
+            if (ballot(lit) != 0ull) {
 #pragma unroll
-                    for (int j = 0; j < SHP / 4; ++j) {
-                        float x[4];
+                for (int half = 0; half < 64 / STAGE_LANES; ++half) {
+                    const bool mine = lit && (STAGE_LANES == 64 || (int)(lane >> 5) == half);
+                    unsigned long long todo = ballot(mine);
+                    if (todo == 0ull) continue;
+                    const uint32_t sl = lane & (uint32_t)(STAGE_LANES - 1);   // staging slot of this lane
+                    if (mine) {
+                        float4 *dst4 = reinterpret_cast<float4 *>(stage + sl * PITCH);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int k = 4 * j + c;
-                            const float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
-                            x[c] = k < NC ? sh[(k < NC ? k : 0) / 3] * gc : 0.0f;
+                        for (int j = 0; j < SHP / 4; ++j) {
+                            float x[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int k = 4 * j + c;
+                                const float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
+                                x[c] = k < NC ? sh[(k < NC ? k : 0) / 3] * gc : 0.0f;
+                            }
+                            dst4[j] = make_float4(x[0], x[1], x[2], x[3]);
                         }
-                        dst4[j] = make_float4(x[0], x[1], x[2], x[3]);
                     }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t col0 = lane & 31u;
-                while (todo != 0ull) {
-                    const uint32_t b0 = (uint32_t)__builtin_ctzll(todo);
-                    todo &= todo - 1ull;
-                    uint32_t b1 = 64u;
-                    if (todo != 0ull) {
-                        b1 = (uint32_t)__builtin_ctzll(todo);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t col0 = lane & 31u;
+                    while (todo != 0ull) {
+                        const uint32_t b0 = (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
-                    }
-                    const uint32_t mine = lane < 32u ? b0 : b1;
-                    const uint32_t cell = __shfl(G.cur, (int)(mine & 63u), 64);
-                    if (mine < 64u) {
-                        for (uint32_t col = col0; col < (uint32_t)NC; col += 32u) {
-                            const float v = stage[mine * PITCH + col];
-                            if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * A + col, v);
+                        uint32_t b1 = 64u;
+                        if (todo != 0ull) {
+                            b1 = (uint32_t)__builtin_ctzll(todo);
+                            todo &= todo - 1ull;
+                        }
+                        const uint32_t src = lane < 32u ? b0 : b1;       // the lane whose row this half-wave emits
+                        const uint32_t cell = __shfl(G.cur, (int)(src & 63u), 64);
+                        if (src < 64u) {
+                            const uint32_t slot = src & (uint32_t)(STAGE_LANES - 1);
+                            for (uint32_t col = col0; col < (uint32_t)NC; col += 32u) {
+                                const float v = stage[slot * PITCH + col];
+                                if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * A + col, v);
+                            }
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();   // the slots are rewritten by the next half / next step
                 }
-                __builtin_amdgcn_wave_barrier();   // the slots are rewritten next step
             }
         }
         G.has = false;
