@@ -5,7 +5,7 @@
 // (offsets[i], offsets[i+1] -> face table -> adjacency[e] -> points[j]); rf_prepare_foam re-lays
 // the foam so that a hop costs ONE dependent round trip and the face scan no unpacking:
 //
-//   workspace = [ float4 cells[N] | half geo[3 * EB] | Link link[EB] | uint32 poff[N+1] |
+//   workspace = [ float4 cells[N] | half geo[3 * EB] | Link link[EB] | uint32 nbr[EB] | uint32 poff[N+1] |
 //                 uint32 scan scratch | SH rows[N][sh_stride] (optional) ]
 //
 //   Every cell's face list is padded to a multiple of 4 entries; poff[i] is the first (padded)
@@ -22,6 +22,8 @@
 //   link[e]    {adj[e], poff[adj[e]], padded face count of adj[e]}, 12 B: the neighbour, where its
 //              faces start and how many -- read once per hop, for the winning face only; the next
 //              cell's face list, cell record and SH row can then all be requested at once.
+//   nbr[e]     adj[e] again (kNone for padding entries), 4 B: what the geometry-only repack streams instead of
+//              the 12-B links when only the points moved (an optimiser step between two triangulation rebuilds)
 //   SH rows    the 3B colour coefficients of a cell, 16-B aligned rows of sh_stride scalars;
 //              present only when the caller's row pitch (A scalars) is not 16-B aligned
 //              (d=1,3); otherwise the kernels read the caller's attribute rows in place.
@@ -45,6 +47,7 @@ struct FoamLayout {
     size_t cells_off;
     size_t geo_off;
     size_t link_off;
+    size_t nbr_off;
     size_t poff_off;
     size_t scan_off;     // per-chunk sums of the prefix sum
     size_t max_entries;  // EB: upper bound of the padded entry count
@@ -76,6 +79,8 @@ inline FoamLayout foam_layout(uint32_t num_points, uint32_t adj_size, int sh_deg
     off = align_up(off + (L.max_entries + kFacePad) * 6, 256);
     L.link_off = off;
     off = align_up(off + L.max_entries * 12, 256);
+    L.nbr_off = off;
+    off = align_up(off + L.max_entries * 4, 256);
     L.poff_off = off;
     off = align_up(off + ((size_t)num_points + 1) * 4, 256);
     L.scan_off = off;

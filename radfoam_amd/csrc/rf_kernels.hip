@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(256) void prepare_foam_kernel(
     const float *__restrict__ points, const void *__restrict__ attributes, uint32_t attr_dim,
     uint32_t num_points, const uint32_t *__restrict__ adj, const uint32_t *__restrict__ offsets,
     const uint32_t *__restrict__ poff, const uint2 *__restrict__ ext_diff, float4 *__restrict__ cells,
-    uint16_t *__restrict__ geo, Link *__restrict__ link) {
+    uint16_t *__restrict__ geo, Link *__restrict__ link, uint32_t *__restrict__ nbr) {
     __shared__ uint32_t s_off[4][66];
     __shared__ uint32_t s_csr[4][66];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1750,17 +1750,22 @@ __global__ __launch_bounds__(256) void prepare_foam_kernel(
         g[4] = (uint16_t)(d.x >> 16);
         g[8] = (uint16_t)(d.y & 0xFFFFu);
         link[f] = lk;
+        nbr[f] = lk.count != 0u ? lk.nbr : kNone;
     }
 }
 
-// Geometry-only repack: the padded offsets and the links of a workspace depend on the adjacency
-// alone, so while the triangulation is unchanged (every optimiser step between two rebuilds) only
-// the cell records and the fp16 face offsets are rewritten.  Same ownership scheme as above; the
-// neighbour of an entry comes from its link (count 0 marks a padding entry).
+// Geometry-only repack: the padded offsets, the links and the neighbour list of a workspace depend on the
+// adjacency alone, so while the triangulation is unchanged (every optimiser step between two rebuilds) only the
+// cell records and the fp16 face offsets are rewritten.  A wave owns 64 consecutive cells; a lane takes one
+// 4-entry block at a time (blocks never straddle cells: lists are padded to 4): one 16-byte read of the four
+// neighbour indices, four point gathers (L2-resident: 24 MB), one 24-byte planar block written as three 8-byte
+// stores; the owner cell comes from a binary search in the wave's 65 padded offsets (LDS), once per block.
+// Streams 4 B in + 6 B out per entry (the first version walked the 12-byte links entry by entry with 2-byte
+// stores: 0.26 ms for the 2M-point foam, 1.2 GB of traffic).
 template <bool HALF>
 __global__ __launch_bounds__(256) void prepare_geometry_kernel(
     const float *__restrict__ points, const void *__restrict__ attributes, uint32_t attr_dim,
-    uint32_t num_points, const uint32_t *__restrict__ poff, const Link *__restrict__ link,
+    uint32_t num_points, const uint32_t *__restrict__ poff, const uint32_t *__restrict__ nbr,
     float4 *__restrict__ cells, uint16_t *__restrict__ geo) {
     __shared__ uint32_t s_off[4][66];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1776,25 +1781,33 @@ __global__ __launch_bounds__(256) void prepare_geometry_kernel(
         cells[i] = make_float4(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2], s);
     }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t f_begin = off[0], f_end = off[ncells];
-    for (uint32_t f = f_begin + lane; f < f_end; f += 64u) {
-        uint32_t lo = 0, hi = ncells;
+    const uint32_t b_begin = off[0] >> 2, b_end = off[ncells] >> 2;
+    for (uint32_t b = b_begin + lane; b < b_end; b += 64u) {
+        const uint32_t f = b << 2;
+        uint32_t lo = 0, hi = ncells;   // owner: last cell whose first entry is <= f
         while (hi - lo > 1u) {
             const uint32_t mid = (lo + hi) >> 1;
             if (off[mid] <= f) lo = mid; else hi = mid;
         }
-        const Link lk = link[f];
-        uint2 d = make_uint2(0u, 0u);
-        if (lk.count != 0u) {
-            const uint32_t i = c0 + lo, q = lk.nbr;
-            const float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
-            const float qx = points[3 * (size_t)q], qy = points[3 * (size_t)q + 1], qz = points[3 * (size_t)q + 2];
-            d = pack_diff(qx - px, qy - py, qz - pz);
+        const uint32_t i = c0 + lo;
+        const float px = points[3 * (size_t)i], py = points[3 * (size_t)i + 1], pz = points[3 * (size_t)i + 2];
+        const uint4 q4 = *reinterpret_cast<const uint4 *>(nbr + f);
+        const uint32_t q[4] = {q4.x, q4.y, q4.z, q4.w};
+        uint16_t hx[4], hy[4], hz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hx[j] = hy[j] = hz[j] = (uint16_t)0;
+            if (q[j] != kNone) {
+                const float *qp = points + 3 * (size_t)q[j];
+                hx[j] = float_to_half_bits(qp[0] - px);
+                hy[j] = float_to_half_bits(qp[1] - py);
+                hz[j] = float_to_half_bits(qp[2] - pz);
+            }
         }
-        uint16_t *g = geo + (size_t)(f >> 2) * 12u + (f & 3u);
-        g[0] = (uint16_t)(d.x & 0xFFFFu);
-        g[4] = (uint16_t)(d.x >> 16);
-        g[8] = (uint16_t)(d.y & 0xFFFFu);
+        uint2 *g = reinterpret_cast<uint2 *>(geo + (size_t)b * 12u);
+        g[0] = make_uint2((uint32_t)hx[0] | ((uint32_t)hx[1] << 16), (uint32_t)hx[2] | ((uint32_t)hx[3] << 16));
+        g[1] = make_uint2((uint32_t)hy[0] | ((uint32_t)hy[1] << 16), (uint32_t)hy[2] | ((uint32_t)hy[3] << 16));
+        g[2] = make_uint2((uint32_t)hz[0] | ((uint32_t)hz[1] << 16), (uint32_t)hz[2] | ((uint32_t)hz[3] << 16));
     }
 }
 
@@ -1858,6 +1871,7 @@ static int prepare_impl(int sh_degree, int attr_type, uint32_t num_points, const
     float4 *cells = reinterpret_cast<float4 *>(base + L.cells_off);
     uint16_t *geo = reinterpret_cast<uint16_t *>(base + L.geo_off);
     Link *link = reinterpret_cast<Link *>(base + L.link_off);
+    uint32_t *nbr = reinterpret_cast<uint32_t *>(base + L.nbr_off);
     uint32_t *poff = reinterpret_cast<uint32_t *>(base + L.poff_off);
     uint32_t *sums = reinterpret_cast<uint32_t *>(base + L.scan_off);
     const uint32_t A = attribute_dim(sh_degree);
@@ -1866,10 +1880,10 @@ static int prepare_impl(int sh_degree, int attr_type, uint32_t num_points, const
     if (topology_valid && !ext_diff) {
         if (half)
             hipLaunchKernelGGL(prepare_geometry_kernel<true>, grid, block, 0, stream, points, attributes, A,
-                               num_points, poff, link, cells, geo);
+                               num_points, poff, nbr, cells, geo);
         else
             hipLaunchKernelGGL(prepare_geometry_kernel<false>, grid, block, 0, stream, points, attributes, A,
-                               num_points, poff, link, cells, geo);
+                               num_points, poff, nbr, cells, geo);
     } else {
         // padded offsets; chunks cover cells 0..num_points inclusive (the last entry is the total)
         const uint32_t nchunks = num_points / kScanChunk + 1u;
@@ -1878,10 +1892,10 @@ static int prepare_impl(int sh_degree, int attr_type, uint32_t num_points, const
         hipLaunchKernelGGL(padded_offsets_kernel, dim3(nchunks), block, 0, stream, offsets, num_points, sums, poff);
         if (half)
             hipLaunchKernelGGL(prepare_foam_kernel<true>, grid, block, 0, stream, points, attributes, A, num_points,
-                               adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link);
+                               adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link, nbr);
         else
             hipLaunchKernelGGL(prepare_foam_kernel<false>, grid, block, 0, stream, points, attributes, A, num_points,
-                               adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link);
+                               adj, offsets, poff, static_cast<const uint2 *>(ext_diff), cells, geo, link, nbr);
     }
     if (L.sh_repacked) {
         size_t total = (size_t)num_points * L.sh_stride;

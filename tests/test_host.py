@@ -53,11 +53,11 @@ def test_host_only_entry_points():
     lib = _lib.load()
     assert [lib.rf_attribute_dim(d) for d in range(-1, 5)] == [0, 4, 13, 28, 49, 0]
     n, e = 1000, 15500
-    # padded entry bound EB = E + 3N: 16-B cells + (EB+32) 6-B geo entries + EB 12-B links + padded offsets
+    # padded entry bound EB = E + 3N: 16-B cells + (EB+32) 6-B geo entries + EB 12-B links + EB 4-B neighbours + padded offsets
     # + prefix-sum scratch (+ repacked SH rows when the pitch is not 16-B aligned)
     eb = e + 3 * n
-    base = 16 * n + 6 * (eb + 32) + 12 * eb + 4 * (n + 1) + 4 * (n // 1024 + 2)
-    assert base <= lib.rf_workspace_bytes(n, e, 2, 0) < base + 5 * 256
+    base = 16 * n + 6 * (eb + 32) + 12 * eb + 4 * eb + 4 * (n + 1) + 4 * (n // 1024 + 2)
+    assert base <= lib.rf_workspace_bytes(n, e, 2, 0) < base + 6 * 256
     assert lib.rf_workspace_bytes(n, e, 1, 0) >= base + n * 12 * 4
     assert lib.rf_workspace_bytes(n, e, 3, 1) >= base + n * 48 * 2
     assert lib.rf_workspace_bytes(n, e, 7, 0) == 0 and lib.rf_workspace_bytes(n, e, 2, 5) == 0
