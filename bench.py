@@ -209,17 +209,18 @@ def main():
     # never set by the driver; a run that uses it says so in its JSON and measures nothing.
     test_factory = os.environ.get("RF_BENCH_TEST_PIPELINE")
     on_gpu = test_factory is None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the tracer has no CPU path")
         dev = torch.device("cuda", local_rank)
-        torch.cuda.set_device(dev)
+        torch.cuda.set_device(dev)     # before the process group: RCCL binds its communicator to the current device
     else:
         dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {"device_id": dev} if (on_gpu and args.backend == "nccl") else {}
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
 
     from radfoam_amd import dist as rdist
     from radfoam_amd import foam

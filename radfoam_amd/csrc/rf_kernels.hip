@@ -411,7 +411,10 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 #ifndef RF_FWD_WAVES_OTHER
 #define RF_FWD_WAVES_OTHER 4
 #endif
-constexpr int forward_waves(int deg, bool quant, bool stats) { return (deg <= 2 && !quant && !stats) ? 6 : RF_FWD_WAVES_OTHER; }
+#ifndef RF_FWD_WAVES_MAIN
+#define RF_FWD_WAVES_MAIN 6
+#endif
+constexpr int forward_waves(int deg, bool quant, bool stats) { return (deg <= 2 && !quant && !stats) ? RF_FWD_WAVES_MAIN : RF_FWD_WAVES_OTHER; }
 
 template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS>
 __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forward_kernel(FwdParams p) {

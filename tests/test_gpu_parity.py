@@ -365,6 +365,25 @@ def test_large_image_properties(foam_factory):
         assert rel < 1e-4, (k, rel)
 
 
+def test_baseline_config_1():
+    """BASELINE.json configs[0] as a parity case: 8,192-point foam (seed 0), 256x256 frame, SH degree 0,
+    forward only.  SURVEY 8(d) describes it as the reference's CPU-runnable plumbing case; the product has no CPU
+    path, so the same inputs go through the HIP path and must equal the CPU oracle bit for bit."""
+    from radfoam_amd import foam
+    d = 0
+    fm = foam.make_synthetic_foam(8192, d, 0)
+    cam, rays, start = H.camera_setup(fm, 256, 256)
+    ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                          fm["point_adjacency_offsets"], rays, start, return_contribution=True)
+    got, _ = _run_forward(_pipeline(d), fm, rays, start, return_contribution=True)
+    np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+    np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32).reshape(-1),
+                                  ref["num_intersections"].reshape(-1))
+    ok, rel, worst = H.grad_close(got["contribution"].numpy(), ref["contribution"])
+    assert ok and rel < 1e-5, (rel, worst)
+    assert ref["rgba"][..., 3].max() > 0.5
+
+
 def _full_size_cases():
     """BASELINE.json configs at their full size: config 2 (500k points, seed 1) always -- Qhull on 500k
     points takes about half a minute when the foam is not cached; the 2M-point north-star foam (seed 5)
