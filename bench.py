@@ -83,6 +83,9 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--quantiles", type=int, default=0,
+                    help="depth quantiles per ray (train.py:176-180 draws 2 per ray, sorted descending, and backpropagates "
+                         "through the depths); 0 = the headline configuration of SURVEY 8(d)")
     ap.add_argument("--backward-mode", type=int, default=0)
     ap.add_argument("--weak", action="store_true", help="N>1: one frame per rank instead of one frame cut by rows")
     ap.add_argument("--exchange", choices=["sparse", "dense"], default="sparse")
@@ -103,6 +106,7 @@ def resolve_workload(args):
     if args.forward_only:
         w["forward_only"] = True
     w["name"] = args.workload
+    w["nq"] = int(args.quantiles)
     return w
 
 
@@ -256,6 +260,11 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(1234 + (rank if (world > 1 and not strong) else 0))
     grad_rgba = torch.randn(rays.shape[:-1] + (4,), generator=gen).to(dev)
     frame_rays = rays.numel() // 6
+    nq = int(args.quantiles) if W["kind"] != "render" else 0
+    quantiles = depth_grad = None
+    if nq:
+        quantiles = torch.rand(rays.shape[:-1] + (nq,), generator=gen).sort(dim=-1, descending=True).values.to(dev)
+        depth_grad = torch.randn(rays.shape[:-1] + (nq,), generator=gen).to(dev)
 
     if on_gpu:
         import radfoam
@@ -311,9 +320,9 @@ def main():
         if record:
             e0.record()
         if strong:
-            out = tracer.forward(points, attributes, adjacency, offsets, rays, start)
+            out = tracer.forward(points, attributes, adjacency, offsets, rays, start, depth_quantiles=quantiles)
         else:
-            out = pipe.trace_forward(points, attributes, adjacency, offsets, rays, start)
+            out = pipe.trace_forward(points, attributes, adjacency, offsets, rays, start, depth_quantiles=quantiles)
         if record:
             e1.record()
         res = None
@@ -321,9 +330,12 @@ def main():
             if strong:
                 g_local = rdist.shard_rows(grad_rgba, rank, world, bounds=tracer.bounds)
                 res = tracer.pipeline.trace_backward(points, attributes, adjacency, offsets, tracer._shard(rays),
-                                                     tracer._shard(start), out["rgba"], g_local)
+                                                     tracer._shard(start), out["rgba"], g_local,
+                                                     tracer._shard(quantiles), out.get("depth_indices"),
+                                                     tracer._shard(depth_grad))
             else:
-                res = pipe.trace_backward(points, attributes, adjacency, offsets, rays, start, out["rgba"], grad_rgba)
+                res = pipe.trace_backward(points, attributes, adjacency, offsets, rays, start, out["rgba"], grad_rgba,
+                                          quantiles, out.get("depth_indices"), depth_grad)
             if record:
                 e2.record()
             if world > 1:
@@ -401,7 +413,7 @@ def main():
         my_start = tracer._shard(start) if strong else start
         stats = pipe.walk_statistics(points, attributes, adjacency, offsets, my_rays, my_start, visit_marks=True)
         visited = stats.pop("visited")
-        bytes_fwd, bytes_bwd = algorithmic_bytes(stats, local_rays, A)
+        bytes_fwd, bytes_bwd = algorithmic_bytes(stats, local_rays, A, nq=nq)
         deg = (offsets[1:].to(torch.int64) - offsets[:-1].to(torch.int64))
         padded = (deg + 3) // 4 * 4
         n_vis = int(visited.sum())
@@ -455,7 +467,8 @@ def main():
     else:
         par = f"one frame per GPU ({world} frames), foam replicated" + ("" if W["forward_only"] else ", dense all-reduce")
     metric = "Mrays/s fwd+bwd @1080p, 2M-pt foam; achieved HBM GB/s vs peak" if W["name"] == "north-star" and not \
-        W.get("custom") and not W["forward_only"] else f"Mrays/s {mode}, {W['label']}"
+        W.get("custom") and not W["forward_only"] and not nq else f"Mrays/s {mode}, {W['label']}" + \
+        (f", {nq} depth quantiles per ray" if nq else "")
     result = {
         "metric": metric,
         "value": round(value, 3),
@@ -471,7 +484,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{W['label']}: synthetic {W['points']}-point foam (seed {W['seed']}), SH degree {sh_degree} "
-                        f"(A={A}), {'fp16' if attr_dtype == torch.float16 else 'fp32'} attrs, {shape}, {mode}",
+                        f"(A={A}), {'fp16' if attr_dtype == torch.float16 else 'fp32'} attrs, {shape}, {mode}"
+                        + (f", {nq} depth quantiles per ray with depth gradients (as train.py:176-180)" if nq else ""),
             "num_points": W["points"], "sh_degree": sh_degree, "rays_per_step": total_rays,
             "weight_threshold": 0.05 if W["kind"] == "render" else 1e-3, "max_intersections": 1024,
             "parallelism": par,
@@ -490,7 +504,7 @@ def main():
     if on_gpu and not args.no_cpu_baseline and world == 1 and W["kind"] != "render":
         try:
             result["cpu_baseline"] = cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba,
-                                                  (points, attributes, adjacency, offsets))
+                                                  (points, attributes, adjacency, offsets), quantiles, depth_grad)
         except Exception as exc:  # the baseline must never take the bench line down
             result["cpu_baseline"] = {"error": repr(exc)}
     print(json.dumps(result), flush=True)
@@ -511,7 +525,7 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
     * ``algorithmic_GBps`` -- SURVEY 8(d)'s logical bytes (no cache credit) / launch time: a throughput that
       may exceed the HBM peak because the walk is served from L1/L2, NOT a fraction of anything.
     """
-    counters = load_counters(W["name"], W.get("custom")) if world == 1 else None
+    counters = load_counters(W["name"], W.get("custom") or W.get("nq")) if world == 1 else None
     per_kernel = {}
     legs = [("forward_kernel", fwd_ms, bytes_fwd, comp_fwd)]
     if bwd_ms > 0:
@@ -563,7 +577,7 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
     return out
 
 
-def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev):
+def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev, quantiles=None, depth_grad=None):
     """Oracle (kind 'port') on a strided sample of the same rays, all host cores; the sample's rgba must equal
     the GPU's bit for bit and its gradients must match a HIP backward of the same sample within the north
     star's 1e-3 (per element, tests/helpers.grad_close) -- over the WHOLE frame when the sample is the frame."""
@@ -577,6 +591,8 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
     diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"], pad=32)
     foam_args = (sh_degree, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
     g_np = grad_rgba.cpu().numpy()
+    q_np = None if quantiles is None else quantiles.cpu().numpy()
+    dg_np = None if depth_grad is None else depth_grad.cpu().numpy()
     total = rays_np.size // 6
 
     def sample(stride):
@@ -584,18 +600,20 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
             sl = (slice(None, None, stride), slice(None, None, stride))
         else:
             sl = (slice(None, None, stride * stride),)
-        return np.ascontiguousarray(rays_np[sl]), np.ascontiguousarray(start_np[sl]), np.ascontiguousarray(g_np[sl]), sl
+        cut = lambda a: None if a is None else np.ascontiguousarray(a[sl])
+        return cut(rays_np), cut(start_np), cut(g_np), sl, cut(q_np), cut(dg_np)
 
     def run(stride):
-        r, s, g, sl = sample(stride)
+        r, s, g, sl, q, dg = sample(stride)
         t0 = time.perf_counter()
-        f = O.trace_forward(*foam_args, r, s, diff=diff)
+        f = O.trace_forward(*foam_args, r, s, depth_quantiles=q, diff=diff)
         t1 = time.perf_counter()
         b = None
         if not W["forward_only"]:
-            b = O.trace_backward(*foam_args, r, s, f["rgba"], g, diff=diff)
+            b = O.trace_backward(*foam_args, r, s, f["rgba"], g, depth_quantiles=q, depth_indices=f.get("depth_indices"),
+                                 depth_grad_in=dg, diff=diff)
         t2 = time.perf_counter()
-        return r.size // 6, t1 - t0, t2 - t1, f, b, (r, s, g, sl)
+        return r.size // 6, t1 - t0, t2 - t1, f, b, (r, s, g, sl, q, dg)
 
     stride = 24
     n, tf, tb, f, b, smp = run(stride)
@@ -609,9 +627,13 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
             break
         stride = new_stride
         n, tf, tb, f, b, smp = run(stride)
-    r, s, g, sl = smp
+    r, s, g, sl, q, dg = smp
     gpu_rgba = last["out"]["rgba"].cpu().numpy()[sl]
     same = bool(np.array_equal(f["rgba"].view(np.uint32), gpu_rgba.view(np.uint32)))
+    if q is not None:   # depths and the cells they fall in are forward outputs too: bit for bit
+        same = same and bool(np.array_equal(f["depth"].view(np.uint32), last["out"]["depth"].cpu().numpy()[sl].view(np.uint32)))
+        same = same and bool(np.array_equal(f["depth_indices"].view(np.uint32).reshape(-1),
+                                            last["out"]["depth_indices"].cpu().numpy()[sl].view(np.uint32).reshape(-1)))
     out = {
         "value": round(n / (tf + tb) / 1e6, 5),
         "unit": "Mrays/s",
@@ -632,8 +654,11 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
         else:
             dev = foam_dev[0].device
             tr, ts = torch.from_numpy(r).to(dev), torch.from_numpy(s).to(dev)
-            fo = pipe.trace_forward(*foam_dev, tr, ts)
-            res = pipe.trace_backward(*foam_dev, tr, ts, fo["rgba"], torch.from_numpy(g).to(dev))
+            tq = None if q is None else torch.from_numpy(q).to(dev)
+            tdg = None if dg is None else torch.from_numpy(dg).to(dev)
+            fo = pipe.trace_forward(*foam_dev, tr, ts, depth_quantiles=tq)
+            res = pipe.trace_backward(*foam_dev, tr, ts, fo["rgba"], torch.from_numpy(g).to(dev), tq,
+                                      fo.get("depth_indices"), tdg)
             where = "a HIP forward+backward of the same sampled rays and upstream gradients"
         out["grad_checked_on"] = where
         for key in ("points_grad", "attr_grad"):

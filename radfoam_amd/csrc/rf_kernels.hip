@@ -406,15 +406,22 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 
 // Waves per SIMD the register allocation is told to aim for: 6 (80 VGPRs, no spills) for the plain
 // instances up to SH degree 2 -- measured 3 % faster than leaving the choice to the compiler, which
-// lands on the same occupancy with a worse schedule -- and 4 where quantile / statistics code or the
-// 16 SH basis values of degree 3 would spill at 80.
+// lands on the same occupancy with a worse schedule; 7 / 8 (72 / 64 VGPRs, a few spills) measured 1-2 % slower --,
+// 5 for the plain SH-degree-3 instances (96 VGPRs, 11 dwords spilled outside the scan: 4M-point 4K frame 23.5 ->
+// 22.2 ms; 6 waves: 22.8) and 4 where quantile / statistics code is compiled in.
 #ifndef RF_FWD_WAVES_OTHER
 #define RF_FWD_WAVES_OTHER 4
 #endif
 #ifndef RF_FWD_WAVES_MAIN
 #define RF_FWD_WAVES_MAIN 6
 #endif
-constexpr int forward_waves(int deg, bool quant, bool stats) { return (deg <= 2 && !quant && !stats) ? RF_FWD_WAVES_MAIN : RF_FWD_WAVES_OTHER; }
+#ifndef RF_FWD_WAVES_D3
+#define RF_FWD_WAVES_D3 5
+#endif
+constexpr int forward_waves(int deg, bool quant, bool stats) {
+    if (quant || stats) return RF_FWD_WAVES_OTHER;
+    return deg <= 2 ? RF_FWD_WAVES_MAIN : RF_FWD_WAVES_D3;
+}
 
 template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS>
 __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forward_kernel(FwdParams p) {
