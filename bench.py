@@ -553,13 +553,27 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
         per_kernel[name] = k
     dom = max(legs, key=lambda l: l[1])[0]
     d = per_kernel[dom]
+    # which limit the dominant kernel actually sits at: VALU issue (the image-shaped walks), HBM (the gathers of a
+    # sparse batch's forward), or neither -- the direct-atomics backward of sparse batches waits on the memory-side
+    # atomic units and on dependent gathers with both fractions low; it is labelled as what it is
+    vf, hf = d.get("valu_issue_frac"), d.get("hbm_frac_of_measured_peak")
+    if vf is None and hf is None:
+        bound = "valu_issue"          # no committed counters for this workload: the walk kernels' usual bound
+    elif (vf or 0.0) >= 0.5 and (vf or 0.0) >= (hf or 0.0):
+        bound = "valu_issue"
+    elif (hf or 0.0) >= 0.5:
+        bound = "hbm"
+    else:
+        bound = "latency (memory-side atomics / dependent gathers): neither VALU issue nor HBM bandwidth is near its peak"
+    frac = hf if bound == "hbm" else vf
     out = {
-        "bound": "valu_issue",
+        "bound": bound,
         "kernel": dom,
-        "achieved": d.get("valu_issue_frac"),
-        "peak": 1.0,
-        "unit": "fraction of VALU issue cycles busy = 4*SQ_ACTIVE_INST_VALU quad-cycles / (1024 SIMDs * GRBM_GUI_ACTIVE/8 cycles)",
-        "frac": d.get("valu_issue_frac"),
+        "achieved": (d.get("hbm_measured_GBps") if bound == "hbm" else vf),
+        "peak": (HBM_PEAK_MEASURED_GBS if bound == "hbm" else 1.0),
+        "unit": ("GB/s of measured HBM traffic against the achievable 6290 GB/s" if bound == "hbm" else
+                 "fraction of VALU issue cycles busy = 4*SQ_ACTIVE_INST_VALU quad-cycles / (1024 SIMDs * GRBM_GUI_ACTIVE/8 cycles)"),
+        "frac": frac,
         "traffic": d.get("hbm_bytes_per_launch"),
         "avg_launch_ms": d["avg_launch_ms"],
         "hbm": {"measured_GBps": d.get("hbm_measured_GBps"), "frac_of_spec_peak_8000": d.get("hbm_frac_of_spec_peak"),
