@@ -319,7 +319,15 @@ class ShardedTracer:
         if world == 1:
             self.bounds = None
             return [0, num_rows]
-        cost_local = num_intersections_local.reshape(num_intersections_local.shape[0], -1).to(torch.int64).sum(dim=1)
+        # A wave walks an 8x8 pixel tile until its LONGEST ray ends, so the work of a row is not the sum of its
+        # rays' steps but, per 8-pixel segment, the longest of them (rows of one tile are alike, so summing the rows
+        # of a band gives 8 x the tiles' maxima): measured on the north-star frame, cuts by summed steps left the
+        # ranks 10 % apart at 8 GPUs -- the edge blocks had fewer rows but just as many wave-steps
+        ni = num_intersections_local.reshape(num_intersections_local.shape[0], -1).to(torch.int64)
+        pad = (-ni.shape[1]) % 8
+        if pad:
+            ni = torch.nn.functional.pad(ni, (0, pad))
+        cost_local = ni.view(ni.shape[0], -1, 8).amax(dim=2).sum(dim=1)
         b, e = self.rows(num_rows)
         full = torch.zeros(num_rows, dtype=torch.int64, device=cost_local.device)
         full[b:e] = cost_local

@@ -59,7 +59,8 @@ def timed(fn, reps=args.reps):
 
 
 full = pipe.trace_forward(p, a, adj, off, rays, start)
-row_cost = full["num_intersections"].reshape(1080, -1).to(torch.int64).sum(dim=1).tolist()
+# the cost model of ShardedTracer.rebalance: per 8-pixel segment the longest ray (a wave runs to its longest ray)
+row_cost = full["num_intersections"].reshape(1080, -1).to(torch.int64).view(1080, -1, 8).amax(dim=2).sum(dim=1).tolist()
 ex = rdist.SparseGradExchange()
 pitch = ex._pitch(A)
 out = {"workload": {"num_points": n, "sh_degree": d, "frame": [1080, 1920], "seed": args.seed}, "worlds": {}}
