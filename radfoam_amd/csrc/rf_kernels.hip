@@ -210,27 +210,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-// n / d for two independent quotients with packed FMAs.  This is the instruction sequence hipcc
-// expands an IEEE fp32 divide into (v_rcp_f32, one Newton step on the reciprocal, two residual
-// corrections of the quotient), minus v_div_scale / v_div_fmas / v_div_fixup, which only act when
-// an operand or the quotient is subnormal, huge, zero, infinite or NaN.  For every other input
-// the result is bit-identical to '/'.  In the face scan the excluded cases are planes (almost)
-// parallel to the ray: the candidate then loses against any regular face exactly as the IEEE
-// quotient (inf or a huge number) would, or -- subnormal quotient -- yields a zero-length segment.
-__device__ __forceinline__ v2f div2(v2f n, v2f d) {
-    v2f y0;
-    y0.x = __builtin_amdgcn_rcpf(d.x);
-    y0.y = __builtin_amdgcn_rcpf(d.y);
-    const v2f one = {1.0f, 1.0f};
-    v2f e = fma2(-d, y0, one);
-    v2f y1 = fma2(e, y0, y0);
-    v2f q0 = n * y1;
-    v2f r0 = fma2(-d, q0, n);
-    v2f q1 = fma2(r0, y1, q0);
-    v2f r1 = fma2(-d, q1, n);
-    return fma2(r1, y1, q1);
-}
-
 struct __attribute__((aligned(8))) GeoXY {
     uint32_t x01, x23, y01, y23;
 };
@@ -239,20 +218,26 @@ struct __attribute__((aligned(8))) GeoZ {
 };
 
 // Nearest exit of the ray from the cell whose `cnt` (a multiple of 4, padding included) face
-// entries start at `blk` in the geo table; ascending order, strict '<' (the first minimum wins,
-// like the reference).  Four faces per iteration, branch-free, two at a time in packed fp32
-// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32); a block arrives as one 16-byte and one 8-byte
-// load (blocks are 8-byte aligned, which this hardware serves -- scripts/probe/unaligned.hip).
-// Padding entries have a zero offset: dp = 0, never a candidate.  The winner is tracked relative
-// to the block being scanned (`rel`, inline constants 0..3) and rebased once per iteration,
-// instead of materialising k+j per face.
+// entries start at `blk` in the geo table; the first minimum wins, like the reference.  Four faces per
+// iteration, branch-free, two at a time in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32); a block arrives as
+// one 16-byte and one 8-byte load (blocks are 8-byte aligned, which this hardware serves --
+// scripts/probe/unaligned.hip).  Padding entries have a zero offset: dp = 0, never a candidate.
+//
+// No face is divided.  t = num/dp of two faces is compared by cross-multiplication (num_a*dp_b < num_b*dp_a,
+// both dp > 0: one rounding per product), the running best is kept as the fraction (nb, db), and only the
+// winner's quotient is formed, once per cell, by an IEEE divide -- the canonical evaluation of DESIGN.md
+// section 2, which the CPU checker of the test-suite implements step for step.  Faces go in pairs: both are tested
+// against the running best, the second replaces the first only if strictly nearer.  Per pair 3 packed multiplies,
+// 5 compares and 6 selects instead of 2 v_rcp_f32 + 7 packed + 4 compares + 4 selects for two expanded divides.
+// The winner is tracked relative to the block being scanned (`rel`, inline constants 0..3) and rebased once per
+// iteration, instead of materialising k+j per face.
 __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t cnt, float Px, float Py,
                                                  float Pz, float Ox, float Oy, float Oz, float dx,
                                                  float dy, float dz) {
     ScanResult r;
-    r.t1 = __builtin_inff();
     constexpr int kUnset = -0x40000000;
     int rel = kUnset;
+    float nb = __builtin_inff(), db = 1.0f;   // running best as a fraction: inf/1 loses against any valid face
     const float cx = Px - Ox, cy = Py - Oy, cz = Pz - Oz;   // once per cell, not per face
     const v2f C2x = {cx, cx}, C2y = {cy, cy}, C2z = {cz, cz};
     const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
@@ -263,7 +248,6 @@ __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t c
         const GeoZ B = *reinterpret_cast<const GeoZ *>(src + 4);
         src += 6;
         rel -= 4;
-        float dp[4], t[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const uint32_t wx = h ? A.x23 : A.x01, wy = h ? A.y23 : A.y01, wz = h ? B.z23 : B.z01;
@@ -277,21 +261,24 @@ __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t c
             const v2f vy = fma2(oy, half2, C2y);
             const v2f vz = fma2(oz, half2, C2z);
             const v2f num = fma2(vx, ox, fma2(vy, oy, vz * oz));
-            const v2f q = div2(num, dpp);
-            dp[2 * h] = dpp.x;
-            dp[2 * h + 1] = dpp.y;
-            t[2 * h] = q.x;
-            t[2 * h + 1] = q.y;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bool better = (dp[j] > 0.0f) && (t[j] < r.t1);
-            r.t1 = better ? t[j] : r.t1;
-            rel = better ? j : rel;
+            // both faces against the running best, and the second against the first
+            const v2f db2 = {db, db}, nb2 = {nb, nb};
+            const v2f a = num * db2;                                        // num_j * db
+            const v2f b = dpp * nb2;                                        // nb * dp_j
+            const v2f c = __builtin_shufflevector(num, num, 1, 0) * dpp;    // {num1*dp0, num0*dp1}
+            const bool win0 = (dpp.x > 0.0f) && (a.x < b.x);
+            const bool win1 = (dpp.y > 0.0f) && (a.y < b.y);
+            const bool take1 = win1 && (!win0 || (c.x < c.y));
+            const bool take0 = win0 && !take1;
+            nb = take1 ? num.y : (take0 ? num.x : nb);
+            db = take1 ? dpp.y : (take0 ? dpp.x : db);
+            rel = take1 ? 2 * h + 1 : (take0 ? 2 * h : rel);
         }
     }
     // after a lane's last iteration its block base is cnt - 4
-    r.k = (rel > kUnset / 2) ? (cnt - 4u) + (uint32_t)rel : kNone;
+    const bool found = rel > kUnset / 2;
+    r.k = found ? (cnt - 4u) + (uint32_t)rel : kNone;
+    r.t1 = found ? nb / db : __builtin_inff();
     return r;
 }
 
