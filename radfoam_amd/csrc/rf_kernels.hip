@@ -226,9 +226,10 @@ struct __attribute__((aligned(8))) GeoZ {
 // No face is divided.  t = num/dp of two faces is compared by cross-multiplication (num_a*dp_b < num_b*dp_a,
 // both dp > 0: one rounding per product), the running best is kept as the fraction (nb, db), and only the
 // winner's quotient is formed, once per cell, by an IEEE divide -- the canonical evaluation of DESIGN.md
-// section 2, which the CPU checker of the test-suite implements step for step.  Faces go in pairs: both are tested
-// against the running best, the second replaces the first only if strictly nearer.  Per pair 3 packed multiplies,
-// 5 compares and 6 selects instead of 2 v_rcp_f32 + 7 packed + 4 compares + 4 selects for two expanded divides.
+// section 2, which the CPU checker of the test-suite implements step for step.  Faces go in pairs: the nearer of
+// the pair (the first on a tie) is found by one comparison and tested against the running best by another.  Per pair
+// 2 packed multiplies, 4 compares and 6 selects instead of 2 v_rcp_f32 + 7 packed + 4 compares + 4 selects for two
+// expanded divides.
 // The winner is tracked relative to the block being scanned (`rel`, inline constants 0..3) and rebased once per
 // iteration, instead of materialising k+j per face.
 __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t cnt, float Px, float Py,
@@ -237,7 +238,8 @@ __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t c
     ScanResult r;
     constexpr int kUnset = -0x40000000;
     int rel = kUnset;
-    float nb = __builtin_inff(), db = 1.0f;   // running best as a fraction: inf/1 loses against any valid face
+    v2f best = {1.0f, __builtin_inff()};   // running best as the fraction best.y / best.x = nb / db: inf/1 loses
+                                           // against any valid face
     const float cx = Px - Ox, cy = Py - Oy, cz = Pz - Oz;   // once per cell, not per face
     const v2f C2x = {cx, cx}, C2y = {cy, cy}, C2z = {cz, cz};
     const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
@@ -261,24 +263,25 @@ __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t c
             const v2f vy = fma2(oy, half2, C2y);
             const v2f vz = fma2(oz, half2, C2z);
             const v2f num = fma2(vx, ox, fma2(vy, oy, vz * oz));
-            // both faces against the running best, and the second against the first
-            const v2f db2 = {db, db}, nb2 = {nb, nb};
-            const v2f a = num * db2;                                        // num_j * db
-            const v2f b = dpp * nb2;                                        // nb * dp_j
+            // the nearer face of the pair (the first on a tie, or when the second is no exit) ...
             const v2f c = __builtin_shufflevector(num, num, 1, 0) * dpp;    // {num1*dp0, num0*dp1}
-            const bool win0 = (dpp.x > 0.0f) && (a.x < b.x);
-            const bool win1 = (dpp.y > 0.0f) && (a.y < b.y);
-            const bool take1 = win1 && (!win0 || (c.x < c.y));
-            const bool take0 = win0 && !take1;
-            nb = take1 ? num.y : (take0 ? num.x : nb);
-            db = take1 ? dpp.y : (take0 ? dpp.x : db);
-            rel = take1 ? 2 * h + 1 : (take0 ? 2 * h : rel);
+            // (bitwise, not short-circuit, logic on the predicates: everything is computed for both faces anyway and
+            // the compiler must not turn the selection into branches)
+            const bool v0 = dpp.x > 0.0f, v1 = dpp.y > 0.0f, lt10 = c.x < c.y;
+            const bool w1 = v1 & (!v0 | lt10);
+            const v2f cand = {w1 ? num.y : num.x, w1 ? dpp.y : dpp.x};      // (num, dp) of the pair's winner
+            // ... against the running best, kept as the adjacent pair (db, nb): one packed multiply forms both products
+            const v2f ab = cand * best;                                      // {num_w*db, dp_w*nb}
+            const bool take = (w1 | v0) & (ab.x < ab.y);
+            best.x = take ? cand.y : best.x;
+            best.y = take ? cand.x : best.y;
+            rel = take ? (w1 ? 2 * h + 1 : 2 * h) : rel;
         }
     }
     // after a lane's last iteration its block base is cnt - 4
     const bool found = rel > kUnset / 2;
     r.k = found ? (cnt - 4u) + (uint32_t)rel : kNone;
-    r.t1 = found ? nb / db : __builtin_inff();
+    r.t1 = found ? best.y / best.x : __builtin_inff();
     return r;
 }
 
