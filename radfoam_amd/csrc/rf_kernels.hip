@@ -1187,8 +1187,11 @@ __device__ __forceinline__ void absorb_stage(uint32_t lane, uint32_t key, bool &
     if (ballot(same) == 0ull) return;
     const bool upper = (lane & (uint32_t)BIT) != 0u;
     const float m = (same && !upper) ? 1.0f : 0.0f;
+    // only the lower lane of a pair receives (m = 1), so the value of lane + BIT is all that is needed: one DPP
+    // read per value, written so that it folds into the multiply-add (v_fmac_f32_dpp) instead of a copy, an in-place
+    // DPP move and a separate v_fmac -- three instructions per value per stage, the bulk of a lit wave-step
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = fma_(xor_lane_any<BIT>(v[i]), m, v[i]);
+    for (int i = 0; i < NV; ++i) v[i] = fma_(from_upper_lane<BIT>(v[i]), m, v[i]);
     if (same && upper) act = false;
 }
 

@@ -65,6 +65,19 @@ __device__ __forceinline__ float xor_lane_any(float x) {
     }
 }
 
+// value of lane (l + BIT) for lanes whose bit BIT is clear (BIT in {1,2,4,8}; what the other lanes get is
+// unspecified: 0 where the source falls outside the row).  A single DPP read with bound_ctrl, so that the compiler
+// can fold it into the consuming VOP2 instruction.
+template <int BIT>
+__device__ __forceinline__ float from_upper_lane(float x) {
+    constexpr int ctrl = BIT == 1 ? 0xB1      // quad_perm [1,0,3,2]
+                         : BIT == 2 ? 0x4E    // quad_perm [2,3,0,1]
+                         : BIT == 4 ? 0x104   // row_shl:4  (lane l reads l + 4)
+                                    : 0x108;  // row_shl:8  (lane l reads l + 8)
+    static_assert(BIT == 1 || BIT == 2 || BIT == 4 || BIT == 8, "from_upper_lane: BIT must be 1,2,4,8");
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), ctrl, 0xF, 0xF, true));
+}
+
 template <int BIT>
 __device__ __forceinline__ uint32_t xor_lane_u(uint32_t x) {
     return __builtin_bit_cast(uint32_t, xor_lane_any<BIT>(__builtin_bit_cast(float, x)));
