@@ -248,6 +248,46 @@ int rf_build_adjacency(const uint32_t *tets, uint32_t num_tets, uint32_t num_poi
                        uint32_t *point_adjacency_size, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* ---- triangulation (the Delaunay build itself) ------------------------------------------------ */
+
+/* radfoam.build_aabb_tree (torch_bindings/triangulation_bindings.cpp:117-140; build_aabb_tree,
+ * src/aabb_tree/aabb_tree.cu:192-283): the implicit balanced tree over points that are already in kd-order.
+ * aabb_tree: [pow2_round_up(num_points)][2][3] floats {min, max}; level d (2^d nodes, node k bounding the points
+ * [k << (depth - d), (k + 1) << (depth - d))) starts at node 2^depth - 2^(d+1); indices past num_points repeat the
+ * last point; the last entry is not written (as in the reference). */
+int rf_build_aabb_tree(const float *points, uint32_t num_points, float *aabb_tree, void *stream);
+
+/* sort_points (src/aabb_tree/aabb_tree.cu:62-190), the order Triangulation::rebuild puts the points in before it
+ * builds the tree (delaunay.cu:316): with P = pow2_round_up(N), everything sorted by x, every consecutive P/2
+ * segment by y, every P/4 segment by z, ... down to segments of 2, stable.  permutation[i] = index in `points` of the
+ * i-th point of the order (Triangulation::permutation()); sorted_points[i] = points[permutation[i]]. */
+size_t rf_kd_order_workspace_bytes(uint32_t num_points);
+int rf_kd_order(const float *points, uint32_t num_points, uint32_t *permutation, float *sorted_points,
+                void *workspace, size_t workspace_bytes, void *stream);
+
+/* Triangulation::rebuild + point_adjacency()/point_adjacency_offsets() (src/delaunay/delaunay.h:17-45,
+ * delaunay.cu:273-370): the Delaunay neighbour lists of `points` (kd-ordered, num_points >= 32 like the reference),
+ * every list ascending, as find_adjacency (delaunay.cu:140-229) emits them.  Every point builds its own star
+ * against `aabb_tree` (rf_build_aabb_tree of the same points) with exact predicates; see csrc/rf_star.hpp.
+ *   seed_adjacency / seed_offsets  optional (both or neither): neighbour lists of a previous triangulation of the
+ *       same point count -- the incremental = true case.  They only make the search cheaper; the result is the
+ *       same triangulation either way.
+ *   point_adjacency [adjacency_capacity], point_adjacency_offsets [num_points + 1]: device outputs.
+ *   info: HOST array of 8 words written before returning (the call synchronises the stream, as the reference's
+ *       rebuild does): [0] adjacency size E (the lists are complete only if E <= adjacency_capacity),
+ *       [1] stars that failed (degenerate or cospherical neighbourhood), [2] stars that needed the large instance,
+ *       [3] points that coincide with another point, [4] directed edges whose reverse is missing,
+ *       [5..6] tree nodes visited (low, high word), [7] link insertions.  [1], [3] or [4] non-zero = what the
+ *       reference reports by throwing TriangulationFailedError ("ambiguous triangulation", "duplicate points
+ *       found"): the caller perturbs the points and retries (radfoam_model/scene.py:160-186).
+ *   workspace: rf_delaunay_workspace_bytes(num_points) device bytes. */
+size_t rf_delaunay_workspace_bytes(uint32_t num_points);
+int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float *aabb_tree,
+                          const uint32_t *seed_adjacency, const uint32_t *seed_offsets,
+                          uint32_t *point_adjacency, uint32_t adjacency_capacity,
+                          uint32_t *point_adjacency_offsets, uint32_t *info, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
 /* ---- multi-GPU gradient exchange (radfoam_amd/dist.py; no counterpart: the reference is single-GPU) ---- */
 
 /* Floats per packed gradient row: 1 (cell index, as bits) + 3 (points_grad) + A (attr_grad), rounded up to

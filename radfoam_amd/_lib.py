@@ -84,6 +84,11 @@ SYMBOLS = {
     "rf_build_ray_order": (_INT, [_P, _P, _U32, _P, _P, C.c_size_t, _P]),
     "rf_adjacency_workspace_bytes": (C.c_size_t, [_U32]),
     "rf_build_adjacency": (_INT, [_P, _U32, _U32, _P, _P, _P, _P, C.c_size_t, _P]),
+    "rf_build_aabb_tree": (_INT, [_P, _U32, _P, _P]),
+    "rf_kd_order_workspace_bytes": (C.c_size_t, [_U32]),
+    "rf_kd_order": (_INT, [_P, _U32, _P, _P, _P, C.c_size_t, _P]),
+    "rf_delaunay_workspace_bytes": (C.c_size_t, [_U32]),
+    "rf_delaunay_adjacency": (_INT, [_P, _U32, _P, _P, _P, _P, _U32, _P, _P, _P, C.c_size_t, _P]),
     "rf_adjacency_size": (_INT, [_U32, _P, C.POINTER(_U32), _P]),
     "rf_cast_accumulator": (_INT, [_P, C.c_size_t, _INT, _P, _P]),
     "rf_grad_row_pitch": (_U32, [_U32]),

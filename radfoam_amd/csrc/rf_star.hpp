@@ -1,0 +1,718 @@
+// rf_star.hpp -- the Delaunay star of one point, built on its own (no shared mesh, no atomics).
+//
+// What it replaces: the reference triangulates on the GPU by growing ONE global tetrahedral mesh
+// (src/delaunay/delaunay.cu:273-370: sample_initial_tets -> growth_iteration* -> find_adjacency, with
+// delete_violations.cu for the incremental case): every iteration sorts and de-duplicates global tet / face tables.
+// The tracer consumes only the NEIGHBOUR LISTS of that mesh (point_adjacency, the Voronoi faces of each cell).
+// Here every point computes its own list independently -- one lane, one star -- which needs no global structure at
+// all:
+//
+//   * the star of p_i is kept as its link: a triangulated sphere whose vertices are the neighbours found so far and
+//     whose triangles (a,b,c) stand for the tetrahedra (i,a,b,c); the point at infinity is an ordinary link vertex
+//     (local slot 0), so hull points need no special casing: a "ghost" triangle (a,b,inf) is the hull facet (i,a,b);
+//   * inserting a candidate q removes the triangles whose tetrahedron q conflicts with (q strictly inside the
+//     circumsphere; for a ghost: strictly beyond the facet's plane) and fans the hole to q (Bowyer-Watson on the link);
+//   * a triangle is FINAL once its open circumball (half-space) is known to hold no point at all.  That is asked of
+//     the reference's own AABB tree (build_aabb_tree: an implicit balanced tree over the kd-ordered points) by a
+//     stackless nearest-child-first traversal which returns the conflicting point closest to p_i, or none;
+//   * candidates ("seeds") only make the queries cheap -- the nearest points of the lane's kd-block, or the previous
+//     neighbour list on an incremental rebuild -- they never decide the result: every final triangle is certified.
+//
+// Since a Delaunay edge can only disappear when points are added, a rejected candidate never has to be looked at
+// again, and the loop "take an uncertified triangle, query, insert or certify" terminates with exactly the Delaunay
+// neighbours of p_i in the full point set.
+//
+// Predicates: a float4 sphere cached per triangle settles all but the points within a few 1e-6 of the sphere; those
+// go to the fp64 determinant with a forward error bound, and what that cannot sign is evaluated EXACTLY in 384-bit
+// integer arithmetic (fp32 inputs are dyadic rationals: scaled to a common grid they are 62-bit integers).  The
+// reference carries Shewchuk's expansion arithmetic for the same purpose (src/delaunay/shewchuk.cuh, predicate.cuh).
+//
+// The includer defines RF_STAR_FN / RF_STAR_NOINLINE (function qualifiers) and RF_STAR_NOUNROLL (loop pragma): the
+// HIP translation unit makes them __device__, tests/host_harness compiles the very same text for the host to check
+// the logic without a GPU.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if !defined(RF_STAR_FN) || !defined(RF_STAR_NOINLINE) || !defined(RF_STAR_NOUNROLL)
+#error "define RF_STAR_FN, RF_STAR_NOINLINE and RF_STAR_NOUNROLL before including rf_star.hpp"
+#endif
+
+namespace rf {
+namespace star {
+
+constexpr uint32_t kInfinity = 0xFFFFFFFFu;   // global id of the vertex at infinity; also "no point"
+constexpr int kLeafBits = 2;                  // the search tests buckets of 4 consecutive points directly
+
+enum Status : int {
+    kOk = 0,
+    kOverflow = 1,     // more link vertices / triangles than this instance holds (retried with the large instance)
+    kDegenerate = 2,   // no non-coplanar starting tetrahedron among the seeds
+    kBroken = 3,       // the link stopped being a sphere (cospherical input: the caller perturbs, like the reference)
+    kDuplicate = 4,    // another point has the same coordinates
+};
+
+enum TriFlag : uint8_t { kCertified = 1, kMarked = 2, kSlow = 4, kGhost = 8 };
+
+// reference layout of build_aabb_tree (src/aabb_tree/aabb_tree.cuh:22-30): level d (2^d nodes, node k covering the
+// points [k << (depth-d), (k+1) << (depth-d))) starts at node index 2^depth - 2^(d+1); a node is {min[3], max[3]}.
+struct Tree {
+    const float *nodes;
+    uint32_t n;       // points
+    uint32_t depth;   // log2(pow2_round_up(n))
+};
+
+RF_STAR_FN const float *tree_node(const Tree &tr, uint32_t d, uint32_t k) {
+    return tr.nodes + 6 * ((size_t)(1u << tr.depth) - (size_t)(1u << (d + 1)) + k);
+}
+
+// ---- exact arithmetic ---------------------------------------------------------------------------------------------
+
+// Everything in this section is the rare path (a few predicates in a million): it is written for a small
+// register footprint -- values live in memory, loops stay rolled, helpers are real calls -- so that the kernels
+// around it keep their occupancy.
+struct Big {   // 384-bit two's complement
+    uint64_t w[6];
+};
+
+RF_STAR_FN void mul64(uint64_t a, uint64_t b, uint64_t &hi, uint64_t &lo) {
+    const uint64_t a0 = (uint32_t)a, a1 = a >> 32, b0 = (uint32_t)b, b1 = b >> 32;
+    const uint64_t p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+    const uint64_t mid = (p00 >> 32) + (uint32_t)p01 + (uint32_t)p10;
+    lo = (p00 & 0xFFFFFFFFull) | (mid << 32);
+    hi = p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+}
+
+RF_STAR_NOINLINE void big_set(Big *r, int64_t v) {
+    r->w[0] = (uint64_t)v;
+    const uint64_t fill = v < 0 ? ~0ull : 0ull;
+    RF_STAR_NOUNROLL
+    for (int k = 1; k < 6; ++k) r->w[k] = fill;
+}
+
+// r = a + b or a - b (r may alias a or b)
+RF_STAR_NOINLINE void big_addsub(Big *r, const Big *a, const Big *b, int subtract) {
+    uint64_t carry = subtract ? 1 : 0;
+    const uint64_t flip = subtract ? ~0ull : 0ull;
+    RF_STAR_NOUNROLL
+    for (int k = 0; k < 6; ++k) {
+        const uint64_t x = a->w[k], y = b->w[k] ^ flip;
+        const uint64_t s = x + y;
+        const uint64_t c1 = s < x;
+        const uint64_t s2 = s + carry;
+        const uint64_t c2 = s2 < s;
+        r->w[k] = s2;
+        carry = c1 | c2;
+    }
+}
+
+// r = low 384 bits of a * b: exact whenever the product fits (r must not alias a or b)
+RF_STAR_NOINLINE void big_mul(Big *r, const Big *a, const Big *b) {
+    RF_STAR_NOUNROLL
+    for (int k = 0; k < 6; ++k) r->w[k] = 0;
+    RF_STAR_NOUNROLL
+    for (int i = 0; i < 6; ++i) {
+        uint64_t carry = 0;
+        const uint64_t ai = a->w[i];
+        RF_STAR_NOUNROLL
+        for (int j = 0; i + j < 6; ++j) {
+            uint64_t hi, lo;
+            mul64(ai, b->w[j], hi, lo);
+            const uint64_t s = r->w[i + j] + lo;
+            const uint64_t c1 = s < lo;
+            const uint64_t s2 = s + carry;
+            const uint64_t c2 = s2 < carry;
+            r->w[i + j] = s2;
+            carry = hi + c1 + c2;
+        }
+    }
+}
+
+RF_STAR_NOINLINE int big_sign(const Big *a) {
+    if (a->w[5] >> 63) return -1;
+    uint64_t any = 0;
+    RF_STAR_NOUNROLL
+    for (int k = 0; k < 6; ++k) any |= a->w[k];
+    return any ? 1 : 0;
+}
+
+// fp32 -> mantissa * 2^exponent
+RF_STAR_FN void decompose(float f, int32_t &m, int32_t &e) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    const int32_t be = (int32_t)((u >> 23) & 0xFF);
+    int32_t frac = (int32_t)(u & 0x7FFFFF);
+    if (be == 0) {
+        e = -149;
+    } else {
+        frac |= 0x800000;
+        e = be - 150;
+    }
+    m = (u >> 31) ? -frac : frac;
+}
+
+// `count` coordinates onto one integer grid (62 bits; coordinates more than 2^38 times finer than the coarsest one
+// of the same predicate are snapped to the grid -- far below anything a float32 point cloud resolves)
+RF_STAR_NOINLINE void to_grid(const float *c, int count, int64_t *out) {
+    int32_t emax = -100000, emin = 100000;
+    RF_STAR_NOUNROLL
+    for (int k = 0; k < count; ++k) {
+        int32_t m, e;
+        decompose(c[k], m, e);
+        if (m != 0) {
+            emax = e > emax ? e : emax;
+            emin = e < emin ? e : emin;
+        }
+    }
+    const int32_t elo = emin > emax - 38 ? emin : emax - 38;
+    RF_STAR_NOUNROLL
+    for (int k = 0; k < count; ++k) {
+        int32_t m, e;
+        decompose(c[k], m, e);
+        const int32_t sh = e - elo;
+        int64_t v = 0;
+        if (m != 0) {
+            if (sh >= 0) v = (int64_t)m << sh;
+            else if (sh > -40) v = (int64_t)m >> (-sh);
+        }
+        out[k] = v;
+    }
+}
+
+// r = a * b - c * d
+RF_STAR_NOINLINE void big_minor(Big *r, int64_t a, int64_t b, int64_t c, int64_t d) {
+    Big x, y, t;
+    big_set(&x, a);
+    big_set(&y, b);
+    big_mul(r, &x, &y);
+    big_set(&x, c);
+    big_set(&y, d);
+    big_mul(&t, &x, &y);
+    big_addsub(r, r, &t, 1);
+}
+
+// r = det[x; y; z]
+RF_STAR_NOINLINE void big_det3(Big *r, const int64_t *x, const int64_t *y, const int64_t *z) {
+    Big m, f, t;
+    big_set(r, 0);
+    RF_STAR_NOUNROLL
+    for (int k = 0; k < 3; ++k) {   // cofactors of x[k]: cyclic, so every sign is +
+        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        big_minor(&m, y[k1], z[k2], y[k2], z[k1]);
+        big_set(&f, x[k]);
+        big_mul(&t, &f, &m);
+        big_addsub(r, r, &t, 0);
+    }
+}
+
+// sign of det[a-i; b-i; c-i], exact.  p = {i, a, b, c} as 12 floats.
+RF_STAR_NOINLINE int exact_orient(const float *p) {
+    int64_t g[12];
+    to_grid(p, 12, g);
+    RF_STAR_NOUNROLL
+    for (int k = 3; k < 12; ++k) g[k] -= g[k % 3];
+    Big r;
+    big_det3(&r, g + 3, g + 6, g + 9);
+    return big_sign(&r);
+}
+
+// sign of the 4x4 determinant with rows (X, |X|^2), X = a-i, b-i, c-i, q-i, exact.  p = {i, a, b, c, q}.
+RF_STAR_NOINLINE int exact_insphere(const float *p) {
+    int64_t g[15];
+    to_grid(p, 15, g);
+    RF_STAR_NOUNROLL
+    for (int k = 3; k < 15; ++k) g[k] -= g[k % 3];
+    const int64_t *row = g + 3;   // rows A, B, C, Q
+    Big r, lift, d, t, x, y;
+    big_set(&r, 0);
+    // expansion along the lifted column: row v has sign (-1)^(v + 3), its minor the other three rows in order
+    RF_STAR_NOUNROLL
+    for (int v = 0; v < 4; ++v) {
+        big_set(&lift, 0);
+        RF_STAR_NOUNROLL
+        for (int k = 0; k < 3; ++k) {
+            big_set(&x, row[3 * v + k]);
+            big_set(&y, row[3 * v + k]);
+            big_mul(&t, &x, &y);
+            big_addsub(&lift, &lift, &t, 0);
+        }
+        const int o0 = v == 0 ? 1 : 0, o1 = v <= 1 ? 2 : 1, o2 = v <= 2 ? 3 : 2;
+        big_det3(&d, row + 3 * o0, row + 3 * o1, row + 3 * o2);
+        big_mul(&t, &lift, &d);
+        big_addsub(&r, &r, &t, (v & 1) ? 0 : 1);
+    }
+    return big_sign(&r);
+}
+
+// ---- fp64 filters ---------------------------------------------------------------------------------------------------
+
+struct D3 {
+    double x, y, z;
+};
+
+RF_STAR_FN D3 diff(float ax, float ay, float az, float bx, float by, float bz) {
+    return D3{(double)ax - (double)bx, (double)ay - (double)by, (double)az - (double)bz};
+}
+
+RF_STAR_FN double det3(const D3 &x, const D3 &y, const D3 &z, double &perm) {
+    const double a = y.y * z.z, b = y.z * z.y, c = y.x * z.z, d = y.z * z.x, e = y.x * z.y, f = y.y * z.x;
+    perm = fabs(x.x) * (fabs(a) + fabs(b)) + fabs(x.y) * (fabs(c) + fabs(d)) + fabs(x.z) * (fabs(e) + fabs(f));
+    return x.x * (a - b) - x.y * (c - d) + x.z * (e - f);
+}
+
+// rounding: every difference, product and sum below rounds once; a term of the 3x3 expansion carries at most 6
+// roundings, the 4x4 one at most 16 (relative to the sum of absolute values of its terms, "perm"); 2^-53 per
+// rounding.  The bounds leave a factor of two on top of that count.
+constexpr double kOrientBound = 2.0e-15;     // > 2 * 8 * 2^-53
+constexpr double kInsphereBound = 8.0e-15;   // > 2 * 32 * 2^-53
+
+// sign of det[a-i; b-i; c-i]
+RF_STAR_FN int orient_sign(const float *pi, const float *pa, const float *pb, const float *pc) {
+    const D3 A = diff(pa[0], pa[1], pa[2], pi[0], pi[1], pi[2]);
+    const D3 B = diff(pb[0], pb[1], pb[2], pi[0], pi[1], pi[2]);
+    const D3 C = diff(pc[0], pc[1], pc[2], pi[0], pi[1], pi[2]);
+    double perm;
+    const double d = det3(A, B, C, perm);
+    if (fabs(d) > kOrientBound * perm) return d > 0 ? 1 : -1;
+    const float p[12] = {pi[0], pi[1], pi[2], pa[0], pa[1], pa[2], pb[0], pb[1], pb[2], pc[0], pc[1], pc[2]};
+    return exact_orient(p);
+}
+
+// sign of the insphere determinant (negative = q strictly inside the sphere through i, a, b, c when
+// det[a-i; b-i; c-i] > 0)
+RF_STAR_FN int insphere_sign(const float *pi, const float *pa, const float *pb, const float *pc, const float *pq) {
+    const D3 A = diff(pa[0], pa[1], pa[2], pi[0], pi[1], pi[2]);
+    const D3 B = diff(pb[0], pb[1], pb[2], pi[0], pi[1], pi[2]);
+    const D3 C = diff(pc[0], pc[1], pc[2], pi[0], pi[1], pi[2]);
+    const D3 Q = diff(pq[0], pq[1], pq[2], pi[0], pi[1], pi[2]);
+    const double la = A.x * A.x + A.y * A.y + A.z * A.z, lb = B.x * B.x + B.y * B.y + B.z * B.z;
+    const double lc = C.x * C.x + C.y * C.y + C.z * C.z, lq = Q.x * Q.x + Q.y * Q.y + Q.z * Q.z;
+    double pabc, pabq, pacq, pbcq;
+    const double dabc = det3(A, B, C, pabc), dabq = det3(A, B, Q, pabq);
+    const double dacq = det3(A, C, Q, pacq), dbcq = det3(B, C, Q, pbcq);
+    const double det = (lq * dabc - lc * dabq) + (lb * dacq - la * dbcq);
+    const double perm = lq * pabc + lc * pabq + lb * pacq + la * pbcq;
+    if (fabs(det) > kInsphereBound * perm) return det > 0 ? 1 : -1;
+    const float p[15] = {pi[0], pi[1], pi[2], pa[0], pa[1], pa[2], pb[0], pb[1], pb[2],
+                         pc[0], pc[1], pc[2], pq[0], pq[1], pq[2]};
+    return exact_insphere(p);
+}
+
+// ---- the star -------------------------------------------------------------------------------------------------------
+
+template <int V, int T>
+struct Star {
+    static constexpr int kV = V, kT = T;
+    uint32_t self;
+    int status;
+    int nt;
+    float p[3];
+    // link vertices; slot 0 is the point at infinity
+    uint32_t vg[V];
+    float vx[V], vy[V], vz[V];
+    uint16_t vuse[V];   // triangles using the slot; 0 = free
+    // link triangles (a,b,c), det[a-i; b-i; c-i] > 0
+    uint8_t ta[T], tb[T], tc[T], tf[T];
+    // finite: circumcentre relative to p_i and squared radius; ghost: normal of the facet plane (pointing outwards)
+    float sx[T], sy[T], sz[T], sr[T];
+};
+
+template <int V, int T>
+RF_STAR_FN void star_reset(Star<V, T> &s, uint32_t self, const float *p) {
+    s.self = self;
+    s.status = kOk;
+    s.nt = 0;
+    s.p[0] = p[0];
+    s.p[1] = p[1];
+    s.p[2] = p[2];
+    for (int k = 0; k < V; ++k) s.vuse[k] = 0;
+    s.vg[0] = kInfinity;
+    s.vx[0] = s.vy[0] = s.vz[0] = 0.0f;
+}
+
+template <int V, int T>
+RF_STAR_FN void vertex_xyz(const Star<V, T> &s, int slot, float *out) {
+    out[0] = s.vx[slot];
+    out[1] = s.vy[slot];
+    out[2] = s.vz[slot];
+}
+
+// the two finite vertices (u, v) of a ghost triangle, rotated so that infinity comes last
+template <int V, int T>
+RF_STAR_FN void ghost_edge(const Star<V, T> &s, int t, int &u, int &v) {
+    const int a = s.ta[t], b = s.tb[t], c = s.tc[t];
+    if (c == 0) {
+        u = a;
+        v = b;
+    } else if (a == 0) {
+        u = b;
+        v = c;
+    } else {
+        u = c;
+        v = a;
+    }
+}
+
+template <int V, int T>
+RF_STAR_FN void set_sphere(Star<V, T> &s, int t) {
+    const int a = s.ta[t], b = s.tb[t], c = s.tc[t];
+    uint8_t flags = 0;
+    if (a == 0 || b == 0 || c == 0) {
+        int u, v;
+        ghost_edge(s, t, u, v);
+        const D3 A = diff(s.vx[u], s.vy[u], s.vz[u], s.p[0], s.p[1], s.p[2]);
+        const D3 B = diff(s.vx[v], s.vy[v], s.vz[v], s.p[0], s.p[1], s.p[2]);
+        const double nx = A.y * B.z - A.z * B.y, ny = A.z * B.x - A.x * B.z, nz = A.x * B.y - A.y * B.x;
+        const double nm = fmax(fabs(nx), fmax(fabs(ny), fabs(nz)));
+        const double am = fmax(fabs(A.x), fmax(fabs(A.y), fabs(A.z)));
+        const double bm = fmax(fabs(B.x), fmax(fabs(B.y), fabs(B.z)));
+        flags = kGhost;
+        if (!(nm > 1e-6 * am * bm)) flags |= kSlow;   // i, u, v nearly collinear: the float normal means nothing
+        // scale does not matter for a half-space: keep the normal in float range
+        const double sc = nm > 0 ? 1.0 / nm : 0.0;
+        s.sx[t] = (float)(nx * sc);
+        s.sy[t] = (float)(ny * sc);
+        s.sz[t] = (float)(nz * sc);
+        s.sr[t] = -1.0f;
+    } else {
+        const D3 A = diff(s.vx[a], s.vy[a], s.vz[a], s.p[0], s.p[1], s.p[2]);
+        const D3 B = diff(s.vx[b], s.vy[b], s.vz[b], s.p[0], s.p[1], s.p[2]);
+        const D3 C = diff(s.vx[c], s.vy[c], s.vz[c], s.p[0], s.p[1], s.p[2]);
+        const D3 bc{B.y * C.z - B.z * C.y, B.z * C.x - B.x * C.z, B.x * C.y - B.y * C.x};
+        const D3 ca{C.y * A.z - C.z * A.y, C.z * A.x - C.x * A.z, C.x * A.y - C.y * A.x};
+        const D3 ab{A.y * B.z - A.z * B.y, A.z * B.x - A.x * B.z, A.x * B.y - A.y * B.x};
+        const double det = A.x * bc.x + A.y * bc.y + A.z * bc.z;
+        const double la = A.x * A.x + A.y * A.y + A.z * A.z, lb = B.x * B.x + B.y * B.y + B.z * B.z;
+        const double lc = C.x * C.x + C.y * C.y + C.z * C.z;
+        const double pm = (fabs(A.x) + fabs(A.y) + fabs(A.z)) * (fabs(B.x) + fabs(B.y) + fabs(B.z)) *
+                          (fabs(C.x) + fabs(C.y) + fabs(C.z));
+        if (det > 1e-7 * pm) {
+            const double h = 0.5 / det;
+            const double cx = (la * bc.x + lb * ca.x + lc * ab.x) * h;
+            const double cy = (la * bc.y + lb * ca.y + lc * ab.y) * h;
+            const double cz = (la * bc.z + lb * ca.z + lc * ab.z) * h;
+            s.sx[t] = (float)cx;
+            s.sy[t] = (float)cy;
+            s.sz[t] = (float)cz;
+            s.sr[t] = (float)(cx * cx + cy * cy + cz * cz);
+            if (!(s.sr[t] < 3.0e38f)) flags |= kSlow;
+        } else {   // a sliver: the centre is not trustworthy, every test of this triangle takes the determinant
+            flags |= kSlow;
+            s.sx[t] = s.sy[t] = s.sz[t] = 0.0f;
+            s.sr[t] = 3.4e38f;
+        }
+    }
+    s.tf[t] = flags;
+}
+
+// does the point q (global coordinates) conflict with triangle t?  Exact.
+template <int V, int T>
+RF_STAR_FN bool conflict(const Star<V, T> &s, int t, const float *q) {
+    const float qx = q[0] - s.p[0], qy = q[1] - s.p[1], qz = q[2] - s.p[2];
+    const uint8_t f = s.tf[t];
+    if (f & kGhost) {
+        if (!(f & kSlow)) {
+            const float tx = s.sx[t] * qx, ty = s.sy[t] * qy, tz = s.sz[t] * qz;
+            const float d = tx + ty + tz;
+            const float u = 4e-6f * (fabsf(tx) + fabsf(ty) + fabsf(tz)) + 1e-37f;
+            if (d > u) return true;
+            if (d < -u) return false;
+        }
+        int a, b;
+        ghost_edge(s, t, a, b);
+        float pa[3], pb[3];
+        vertex_xyz(s, a, pa);
+        vertex_xyz(s, b, pb);
+        return orient_sign(s.p, pa, pb, q) > 0;
+    }
+    if (!(f & kSlow)) {
+        const float dx = qx - s.sx[t], dy = qy - s.sy[t], dz = qz - s.sz[t];
+        const float d2 = dx * dx + dy * dy + dz * dz, r2 = s.sr[t];
+        const float u = 4e-6f * (d2 + r2) + 1e-37f;
+        if (d2 > r2 + u) return false;
+        if (d2 < r2 - u) return true;
+    }
+    float pa[3], pb[3], pc[3];
+    vertex_xyz(s, s.ta[t], pa);
+    vertex_xyz(s, s.tb[t], pb);
+    vertex_xyz(s, s.tc[t], pc);
+    return insphere_sign(s.p, pa, pb, pc, q) < 0;
+}
+
+template <int V, int T>
+RF_STAR_FN bool has_directed_edge(const Star<V, T> &s, int t, int u, int v) {
+    const int a = s.ta[t], b = s.tb[t], c = s.tc[t];
+    return (a == u && b == v) || (b == u && c == v) || (c == u && a == v);
+}
+
+// first tetrahedron (i, a, b, c) + its three ghosts.  false: the four points are coplanar.
+template <int V, int T>
+RF_STAR_FN bool star_init(Star<V, T> &s, uint32_t ga, const float *pa, uint32_t gb, const float *pb, uint32_t gc,
+                          const float *pc) {
+    const int o = orient_sign(s.p, pa, pb, pc);
+    if (o == 0) return false;
+    const float *q1 = o > 0 ? pa : pb, *q2 = o > 0 ? pb : pa;
+    s.vg[1] = o > 0 ? ga : gb;
+    s.vg[2] = o > 0 ? gb : ga;
+    s.vg[3] = gc;
+    s.vx[1] = q1[0]; s.vy[1] = q1[1]; s.vz[1] = q1[2];
+    s.vx[2] = q2[0]; s.vy[2] = q2[1]; s.vz[2] = q2[2];
+    s.vx[3] = pc[0]; s.vy[3] = pc[1]; s.vz[3] = pc[2];
+    // (1,2,3), (2,1,inf), (3,2,inf), (1,3,inf): every directed edge once, its reverse once
+    const uint8_t tri[4][3] = {{1, 2, 3}, {2, 1, 0}, {3, 2, 0}, {1, 3, 0}};
+    for (int t = 0; t < 4; ++t) {
+        s.ta[t] = tri[t][0];
+        s.tb[t] = tri[t][1];
+        s.tc[t] = tri[t][2];
+    }
+    s.nt = 4;
+    s.vuse[0] = 3;
+    s.vuse[1] = s.vuse[2] = s.vuse[3] = 3;
+    for (int t = 0; t < 4; ++t) set_sphere(s, t);
+    return true;
+}
+
+// Bowyer-Watson on the link.  Returns the number of triangles removed (0: q is not a neighbour), -1 on failure.
+template <int V, int T>
+RF_STAR_FN int star_insert(Star<V, T> &s, uint32_t gq, const float *q) {
+    const int nt0 = s.nt;
+    int marked = 0;
+    for (int t = 0; t < nt0; ++t)
+        if (conflict(s, t, q)) {
+            s.tf[t] |= kMarked;
+            ++marked;
+        }
+    if (marked == 0) return 0;
+    int slot = -1;
+    for (int k = 1; k < V; ++k)
+        if (s.vuse[k] == 0) {
+            slot = k;
+            break;
+        }
+    if (slot < 0) {
+        s.status = kOverflow;
+        return -1;
+    }
+    s.vg[slot] = gq;
+    s.vx[slot] = q[0];
+    s.vy[slot] = q[1];
+    s.vz[slot] = q[2];
+    // every directed edge of the hole whose reverse is not in the hole lies on its boundary: fan it to q
+    int nt = nt0;
+    for (int t = 0; t < nt0; ++t) {
+        if (!(s.tf[t] & kMarked)) continue;
+        const int v3[4] = {s.ta[t], s.tb[t], s.tc[t], s.ta[t]};
+        for (int e = 0; e < 3; ++e) {
+            const int u = v3[e], v = v3[e + 1];
+            bool inner = false;
+            for (int t2 = 0; t2 < nt0 && !inner; ++t2)
+                inner = (s.tf[t2] & kMarked) && t2 != t && has_directed_edge(s, t2, v, u);
+            if (inner) continue;
+            if (nt >= T) {
+                s.status = kOverflow;
+                return -1;
+            }
+            s.ta[nt] = (uint8_t)u;
+            s.tb[nt] = (uint8_t)v;
+            s.tc[nt] = (uint8_t)slot;
+            s.tf[nt] = 0;
+            ++s.vuse[u];
+            ++s.vuse[v];
+            ++s.vuse[slot];
+            ++nt;
+        }
+    }
+    const int added = nt - nt0;
+    for (int t = nt0; t < nt; ++t) set_sphere(s, t);
+    // drop the hole: move the last live triangle into every marked slot
+    int vanished = 0;   // link vertices that were interior to the hole
+    int t = 0;
+    while (t < nt) {
+        if (!(s.tf[t] & kMarked)) {
+            ++t;
+            continue;
+        }
+        vanished += (--s.vuse[s.ta[t]] == 0) + (--s.vuse[s.tb[t]] == 0) + (--s.vuse[s.tc[t]] == 0);
+        --nt;
+        if (t != nt) {
+            s.ta[t] = s.ta[nt]; s.tb[t] = s.tb[nt]; s.tc[t] = s.tc[nt]; s.tf[t] = s.tf[nt];
+            s.sx[t] = s.sx[nt]; s.sy[t] = s.sy[nt]; s.sz[t] = s.sz[nt]; s.sr[t] = s.sr[nt];
+        }
+    }
+    s.nt = nt;
+    // a hole that is a disc of m triangles around k interior vertices has m + 2 - 2k boundary edges
+    if (added != marked + 2 - 2 * vanished) {
+        s.status = kBroken;
+        return -1;
+    }
+    return marked;
+}
+
+RF_STAR_FN float box_dist2(const float *nd, float x, float y, float z) {
+    const float dx = fmaxf(fmaxf(nd[0] - x, x - nd[3]), 0.0f);
+    const float dy = fmaxf(fmaxf(nd[1] - y, y - nd[4]), 0.0f);
+    const float dz = fmaxf(fmaxf(nd[2] - z, z - nd[5]), 0.0f);
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// The point in strict conflict with triangle t that is closest to p_i, or kInfinity if there is none: depth-first
+// through the implicit tree, nearer child first, boxes pruned against the triangle's ball (half-space) and against
+// the best candidate so far.  `visited` counts tree nodes (instrumentation).
+template <int V, int T>
+RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts, int t, float *out_q,
+                                uint32_t &visited) {
+    const uint8_t f = s.tf[t];
+    const bool ghost = (f & kGhost) != 0;
+    const bool ball = !ghost && !(f & kSlow);
+    const float px = s.p[0], py = s.p[1], pz = s.p[2];
+    const float nx = s.sx[t], ny = s.sy[t], nz = s.sz[t];
+    // ball in absolute coordinates, radius padded for the roundings of centre and box distance
+    const float cx = px + nx, cy = py + ny, cz = pz + nz;
+    float rp2 = 3.4e38f;
+    if (ball) {
+        const float r = sqrtf(s.sr[t]);
+        const float pad = 4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(nx) + fabsf(ny) + fabsf(nz) + r);
+        const float rp = (r + pad) * 1.000002f;
+        rp2 = rp * rp;
+    }
+    const uint32_t g0 = s.vg[s.ta[t]], g1 = s.vg[s.tb[t]], g2 = s.vg[s.tc[t]];
+    const uint32_t leaf_depth = tr.depth - kLeafBits;
+    float best = 3.4e38f;
+    uint32_t best_id = kInfinity;
+    uint32_t depth = 0, vidx = 0, flip = 0;
+    for (;;) {
+        const uint32_t idx = vidx ^ flip;
+        const uint32_t first = idx << (tr.depth - depth);
+        bool descend = false;
+        if (first < tr.n) {
+            const float *nd = tree_node(tr, depth, idx);
+            ++visited;
+            bool ok = box_dist2(nd, px, py, pz) < best;
+            if (ok && ball) ok = box_dist2(nd, cx, cy, cz) <= rp2;
+            if (ok && ghost && !(f & kSlow)) {
+                // largest value of n . (x - p) over the box
+                const float ax = nx > 0 ? nd[3] - px : nd[0] - px, ay = ny > 0 ? nd[4] - py : nd[1] - py;
+                const float az = nz > 0 ? nd[5] - pz : nd[2] - pz;
+                const float tx = nx * ax, ty = ny * ay, tz = nz * az;
+                ok = tx + ty + tz > -4e-6f * (fabsf(tx) + fabsf(ty) + fabsf(tz));
+            }
+            if (ok) {
+                if (depth < leaf_depth) {
+                    descend = true;
+                } else {
+                    const uint32_t end = first + (1u << kLeafBits) < tr.n ? first + (1u << kLeafBits) : tr.n;
+                    for (uint32_t k = first; k < end; ++k) {
+                        if (k == s.self || k == g0 || k == g1 || k == g2) continue;
+                        const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
+                        const float dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        if (d2 == 0.0f && q[0] == px && q[1] == py && q[2] == pz) s.status = kDuplicate;
+                        if (!(d2 < best)) continue;
+                        if (!conflict(s, t, q)) continue;
+                        best = d2;
+                        best_id = k;
+                        out_q[0] = q[0];
+                        out_q[1] = q[1];
+                        out_q[2] = q[2];
+                    }
+                }
+            }
+        }
+        if (descend) {
+            // the children of a level-d node are separated along axis d % 3 (kd-order): nearer one first
+            const uint32_t dim = depth % 3;
+            const float *left = tree_node(tr, depth + 1, 2 * idx);
+            const float pd = dim == 0 ? px : (dim == 1 ? py : pz);
+            const uint32_t right_first = pd > left[3 + dim] ? 1u : 0u;
+            ++depth;
+            vidx <<= 1;
+            flip = (flip << 1) | right_first;
+            continue;
+        }
+        ++vidx;
+        uint32_t up = (uint32_t)__builtin_ctz(vidx);
+        up = up < depth ? up : depth;
+        depth -= up;
+        vidx >>= up;
+        flip >>= up;
+        if (depth == 0) break;
+    }
+    return best_id;
+}
+
+// Build the star from `nseeds` candidate points (any order; nearest first is cheapest), then certify.
+template <int V, int T>
+RF_STAR_FN void star_build(Star<V, T> &s, const Tree &tr, const float *pts, const uint32_t *seeds, int nseeds,
+                           uint32_t &visited, uint32_t &inserted) {
+    // starting tetrahedron: the first seed triple that is not coplanar with p_i
+    int i0 = -1, i1 = -1, i2 = -1;
+    for (int a = 0; a < nseeds && i0 < 0; ++a)
+        for (int b = a + 1; b < nseeds && i0 < 0; ++b)
+            for (int c = b + 1; c < nseeds; ++c) {
+                const float *pa = pts + 3 * (size_t)seeds[a], *pb = pts + 3 * (size_t)seeds[b];
+                const float *pc = pts + 3 * (size_t)seeds[c];
+                if (star_init(s, seeds[a], pa, seeds[b], pb, seeds[c], pc)) {
+                    i0 = a;
+                    i1 = b;
+                    i2 = c;
+                    break;
+                }
+            }
+    if (i0 < 0) {
+        s.status = kDegenerate;
+        return;
+    }
+    for (int k = 0; k < nseeds; ++k) {
+        if (k == i0 || k == i1 || k == i2) continue;
+        const float *q = pts + 3 * (size_t)seeds[k];
+        if (q[0] == s.p[0] && q[1] == s.p[1] && q[2] == s.p[2]) {
+            s.status = kDuplicate;
+            return;
+        }
+        if (star_insert(s, seeds[k], q) < 0) return;
+        ++inserted;
+    }
+    for (;;) {
+        int t = -1;
+        for (int k = 0; k < s.nt; ++k)
+            if (!(s.tf[k] & kCertified)) {
+                t = k;
+                break;
+            }
+        if (t < 0) break;
+        float q[3];
+        const uint32_t j = star_search(s, tr, pts, t, q, visited);
+        if (s.status != kOk) return;
+        if (j == kInfinity) {
+            s.tf[t] |= kCertified;
+            continue;
+        }
+        if (star_insert(s, j, q) <= 0) {
+            if (s.status == kOk) s.status = kBroken;   // the search said "conflict", the insertion must agree
+            return;
+        }
+        ++inserted;
+    }
+}
+
+// Neighbours in ascending order (finite link vertices); returns the count.  *hull = the star has a ghost.
+template <int V, int T>
+RF_STAR_FN int star_neighbours(const Star<V, T> &s, uint32_t *out, int stride, bool *hull) {
+    int n = 0;
+    for (int k = 1; k < V; ++k) {
+        if (s.vuse[k] == 0) continue;
+        const uint32_t g = s.vg[k];
+        int pos = n;
+        while (pos > 0 && out[(size_t)(pos - 1) * stride] > g) {
+            out[(size_t)pos * stride] = out[(size_t)(pos - 1) * stride];
+            --pos;
+        }
+        out[(size_t)pos * stride] = g;
+        ++n;
+    }
+    *hull = s.vuse[0] != 0;
+    return n;
+}
+
+}  // namespace star
+}  // namespace rf

@@ -20,18 +20,22 @@ import torch
 from . import foam as _foam
 
 
-class TriangulationFailedError(RuntimeError):
-    """radfoam::TriangulationFailedError (registered at triangulation_bindings.cpp:222)."""
+from .triangulation import TriangulationFailedError  # noqa: E402  (one class for both triangulations)
 
 
 class Triangulation:
-    """CPU (Qhull) stand-in for the reference's GPU Delaunay.
-
-    Same protocol as the reference class: construction kd-sorts the points and triangulates them
-    in that order; ``permutation()`` tells the caller how to reorder its own arrays;
-    ``rebuild(points)`` expects points already in that order and returns whether a new
-    permutation has to be applied.
+    """``radfoam.Triangulation(points)``.  CUDA float32 points get the GPU triangulation
+    (radfoam_amd/triangulation.py: kd-order, AABB tree and one Delaunay star per point in HIP); CPU tensors get
+    this class, a Qhull stand-in with the same protocol: construction kd-sorts the points and triangulates them
+    in that order; ``permutation()`` tells the caller how to reorder its own arrays; ``rebuild(points)`` expects
+    points already in that order and returns whether a new permutation has to be applied.
     """
+
+    def __new__(cls, points: torch.Tensor):
+        if cls is Triangulation and isinstance(points, torch.Tensor) and points.is_cuda:
+            from .triangulation import Triangulation as GpuTriangulation
+            return GpuTriangulation(points)   # not an instance of cls: __init__ below is not run
+        return super().__new__(cls)
 
     def __init__(self, points: torch.Tensor):
         if points.dim() != 2 or points.size(-1) != 3:
@@ -107,15 +111,18 @@ class Triangulation:
 
 
 def build_aabb_tree(points: torch.Tensor) -> torch.Tensor:
-    """Tensor of the reference's shape [pow2_round_up(N), 2, 3].
-
-    Only ``nn`` consumes it, and this package's ``nn`` is an exact brute-force search, so the
-    tensor just carries the global bounding box (a valid, if useless, bound for every node).
+    """Tensor of the reference's shape [pow2_round_up(N), 2, 3].  CUDA float32 points: the reference's
+    tree itself (bit-identical boxes; the GPU triangulation searches it).  CPU tensors: only ``nn`` would
+    consume it, and this package's ``nn`` is an exact brute-force search, so that tensor just carries the
+    global bounding box (a valid, if useless, bound for every node).
     """
     if points.size(-1) != 3:
         raise RuntimeError("points must have 3 as the last dimension")
     if points.dim() != 2:
         raise RuntimeError("points must have 2 dimensions")
+    if points.is_cuda and points.dtype == torch.float32:
+        from . import triangulation
+        return triangulation.build_aabb_tree(points)   # the reference's tree, HIP (rf_build_aabb_tree)
     n = points.size(0)
     lo = points.min(dim=0).values
     hi = points.max(dim=0).values
