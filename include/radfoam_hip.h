@@ -273,11 +273,13 @@ int rf_kd_order(const float *points, uint32_t num_points, uint32_t *permutation,
  *       same point count -- the incremental = true case.  They only make the search cheaper; the result is the
  *       same triangulation either way.
  *   point_adjacency [adjacency_capacity], point_adjacency_offsets [num_points + 1]: device outputs.
- *   info: HOST array of 8 words written before returning (the call synchronises the stream, as the reference's
+ *   info: HOST array of 12 words written before returning (the call synchronises the stream, as the reference's
  *       rebuild does): [0] adjacency size E (the lists are complete only if E <= adjacency_capacity),
  *       [1] stars that failed (degenerate or cospherical neighbourhood), [2] stars that needed the large instance,
  *       [3] points that coincide with another point, [4] directed edges whose reverse is missing,
- *       [5..6] tree nodes visited (low, high word), [7] link insertions.  [1], [3] or [4] non-zero = what the
+ *       [5..6] tree nodes visited (low, high word), [7] link insertions, [8..10] the failed stars of [1] by cause
+ *       (no non-coplanar start, link no longer a sphere, more than 249 neighbours), [11] hull candidates.
+ *       [1], [3] or [4] non-zero = what the
  *       reference reports by throwing TriangulationFailedError ("ambiguous triangulation", "duplicate points
  *       found"): the caller perturbs the points and retries (radfoam_model/scene.py:160-186).
  *   workspace: rf_delaunay_workspace_bytes(num_points) device bytes. */

@@ -12,8 +12,10 @@
 //                            LDS and give every lane its first candidates (the 12 nearest of the block), or -- on an
 //                            incremental rebuild -- the lane's previous neighbour list does; star state (64 link
 //                            vertices, 124 triangles with cached spheres: 3.6 KB) lives in the lane's scratch
-//   delaunay_star_big_kernel stars that outgrow that (hub points, long hull facets) are redone with room for 250
-//                            neighbours in a global arena, a few hundred of 2M points
+//                            every query has a budget of tree nodes; a star whose query runs out is parked
+//   delaunay_star_coop_kernel second pass, one WAVE per star: the parked stars (rim of the cloud: half-spaces behind
+//                            hull facets and the huge balls of flat tetrahedra, 10^5 tree nodes a query) and stars
+//                            with more than 63 neighbours (room for 249); a few per thousand points
 //   csr_*                    degrees -> offsets (rocPRIM scan) -> adjacency, ascending per point like find_adjacency's
 //   symmetry_kernel          j in N(i) <=> i in N(j): exact predicates make independent stars agree; cospherical
 //                            input can break that, which is reported (the reference throws "ambiguous triangulation")
@@ -39,7 +41,7 @@ namespace rf {
 constexpr int kSmallV = 64, kSmallT = 124;
 constexpr int kBigV = 250, kBigT = 496;
 constexpr int kBlockSeeds = 12;
-constexpr uint32_t kBigFlag = 0x80000000u;   // degree word of a star kept by the large instance: flag | arena slot
+constexpr uint32_t kBigFlag = 0x80000000u;   // first word of the row of a second-pass star: flag | row in big_rows
 
 using SmallStar = star::Star<kSmallV, kSmallT>;
 using BigStar = star::Star<kBigV, kBigT>;
@@ -84,8 +86,9 @@ __global__ __launch_bounds__(256) void aabb_level_kernel(const float *__restrict
 // ---- stars ----------------------------------------------------------------------------------------------------------
 
 struct StarCounters {
-    uint32_t overflow;     // stars handed to the large instance
-    uint32_t failed[5];    // stars by star::Status (index 0 unused)
+    uint32_t overflow;     // stars handed to the second pass (too large for the small instance, or parked)
+    uint32_t hull;         // entries of the hull candidate list
+    uint32_t failed[6];    // stars by star::Status (index 0 unused)
     uint32_t asymmetric;   // directed edges without their reverse
     uint32_t adjacency;    // E
     uint32_t nodes_lo, nodes_hi;   // tree nodes visited (64-bit)
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(const
                                                            const uint32_t *__restrict__ seed_off,
                                                            uint32_t *__restrict__ rows, uint32_t *__restrict__ degree,
                                                            uint32_t *__restrict__ overflow_list,
+                                                           uint32_t *__restrict__ hull_list, uint32_t ghost_budget,
                                                            StarCounters *__restrict__ counters) {
     __shared__ float block_pts[64 * 3];
     const uint32_t block_first = blockIdx.x * 64u;
@@ -155,15 +159,21 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(const
                                                   seeds, kSmallV - 1);
     const star::Tree tr{tree, n, depth};
     uint32_t visited = 0, inserted = 0;
-    star::star_build(s, tr, pts, seeds, ns, visited, inserted);
+    const star::HullSet first_pass{nullptr, 0u, ghost_budget};
+    star::star_build(s, tr, pts, first_pass, seeds, ns, visited, inserted);
     atomicAdd(&counters->inserted, inserted);
     const uint32_t old = atomicAdd(&counters->nodes_lo, visited);
     if (old + visited < old) atomicAdd(&counters->nodes_hi, 1u);
 
-    if (s.status == star::kOverflow) {
-        const uint32_t slot = atomicAdd(&counters->overflow, 1u);
-        overflow_list[slot] = i;
-        degree[i] = 0;
+    if (s.status == star::kOverflow || s.status == star::kPending) {
+        overflow_list[atomicAdd(&counters->overflow, 1u)] = i;
+        hull_list[atomicAdd(&counters->hull, 1u)] = i;   // not known to be interior: a hull candidate
+        // what this pass found so far are the second pass's first candidates
+        uint32_t *row = rows + (size_t)i * kSmallV;
+        uint32_t c = 0;
+        for (int k = 1; k < kSmallV; ++k)
+            if (s.vuse[k]) row[c++] = s.vg[k];
+        degree[i] = c;
         return;
     }
     if (s.status != star::kOk) {
@@ -174,44 +184,211 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(const
     bool hull;
     uint32_t nb[kSmallV];
     const int deg = star::star_neighbours(s, nb, 1, &hull);
+    if (hull) hull_list[atomicAdd(&counters->hull, 1u)] = i;   // a vertex of the convex hull
     uint32_t *row = rows + (size_t)i * kSmallV;
     for (int k = 0; k < deg; ++k) row[k] = nb[k];
     degree[i] = (uint32_t)deg;
 }
 
-// one lane per star the small instance could not hold; state and result rows in global memory
-__global__ __launch_bounds__(64) void delaunay_star_big_kernel(const float *__restrict__ pts, uint32_t n,
-                                                               const float *__restrict__ tree, uint32_t depth,
-                                                               const uint32_t *__restrict__ seed_adj,
-                                                               const uint32_t *__restrict__ seed_off,
-                                                               const uint32_t *__restrict__ overflow_list,
-                                                               uint32_t first, uint32_t count,
-                                                               BigStar *__restrict__ arena,
-                                                               uint32_t *__restrict__ big_rows,
-                                                               uint32_t *__restrict__ degree,
-                                                               StarCounters *__restrict__ counters) {
-    const uint32_t w = blockIdx.x * 64u + threadIdx.x;
+// ---- second pass: one WAVE per star --------------------------------------------------------------------------------
+// Stars the first pass parked (a query ran out of budget: rim of the cloud, rf_star.hpp HullSet) or could not hold.
+// The star (large instance, 14 KB) sits in LDS, thread 0 does the link surgery, the block's waves each take one of
+// the star's open queries, and a query is answered by its whole wave: the tree is walked six levels at a time -- the 64 descendants of a node are consecutive in memory, one
+// box per lane, a ballot keeps those the region touches (the reference's warp_traverse walks its tree the same way,
+// 32 wide: src/aabb_tree/aabb_tree.cuh:77-152) -- and a ghost query is one pass over the hull candidates, 64 at a time.
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+struct CoopResult {
+    uint32_t id;
+    float q[3];
+    bool duplicate;
+};
+
+__device__ CoopResult coop_search(const BigStar &s, const star::Tree &tr, const float *__restrict__ pts, int t,
+                                  const uint32_t *__restrict__ hull_ids, uint32_t hull_count, uint32_t &visited) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint8_t f = s.tf[t];
+    const bool ghost = (f & star::kGhost) != 0;
+    const bool ball = !ghost && s.sr[t] < 3.0e38f;
+    const float px = s.p[0], py = s.p[1], pz = s.p[2];
+    const float nx = s.sx[t], ny = s.sy[t], nz = s.sz[t];
+    const float cx = px + nx, cy = py + ny, cz = pz + nz;
+    float rp2 = 3.4e38f;
+    if (ball) {
+        const float r = sqrtf(s.sr[t]);
+        const float pad = 4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(nx) + fabsf(ny) + fabsf(nz) + r);
+        const float rp = (r + pad) * 1.000002f;
+        rp2 = rp * rp;
+    }
+    const uint32_t g0 = s.vg[s.ta[t]], g1 = s.vg[s.tb[t]], g2 = s.vg[s.tc[t]];
+    float best = 3.4e38f;        // wave-uniform: prunes
+    float my_d2 = 3.4e38f;       // this lane's candidate
+    uint32_t my_id = star::kInfinity;
+    float my_q[3] = {0.0f, 0.0f, 0.0f};
+    bool duplicate = false;
+
+    auto try_point = [&](uint32_t k) {
+        if (k == s.self || k == g0 || k == g1 || k == g2) return;
+        const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
+        const float dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 == 0.0f && q[0] == px && q[1] == py && q[2] == pz) duplicate = true;
+        if (!(d2 < my_d2) || !(d2 < best) || !star::conflict(s, t, q)) return;
+        my_d2 = d2;
+        my_id = k;
+        my_q[0] = q[0];
+        my_q[1] = q[1];
+        my_q[2] = q[2];
+    };
+
+    if (ghost && hull_ids) {
+        for (uint32_t base = 0; base < hull_count; base += 64)
+            if (base + lane < hull_count) try_point(hull_ids[base + lane]);
+        visited += hull_count;
+    } else {
+        const uint32_t leaf_depth = tr.depth - star::kLeafBits;
+        const uint32_t d0 = leaf_depth % 6;
+        unsigned long long mask[6];
+        uint32_t base[6];
+        int level = 0;
+        base[0] = 0;
+        for (;;) {
+            const uint32_t depth = d0 + 6u * (uint32_t)level;
+            const uint32_t width = level == 0 ? (1u << d0) : 64u;
+            const uint32_t idx = base[level] + lane;
+            const uint32_t first = idx << (tr.depth - depth);
+            bool ok = lane < width && first < tr.n;
+            if (ok) {
+                const float *nd = star::tree_node(tr, depth, idx);
+                ok = star::box_dist2(nd, px, py, pz) < best;
+                if (ok && ball) ok = star::box_dist2(nd, cx, cy, cz) <= rp2;
+                if (ok && ghost && !(f & star::kSlow)) {
+                    const float ax = nx > 0 ? nd[3] - px : nd[0] - px, ay = ny > 0 ? nd[4] - py : nd[1] - py;
+                    const float az = nz > 0 ? nd[5] - pz : nd[2] - pz;
+                    const float tx = nx * ax, ty = ny * ay, tz = nz * az;
+                    ok = tx + ty + tz > -4e-6f * (fabsf(tx) + fabsf(ty) + fabsf(tz));
+                }
+            }
+            visited += width;
+            if (depth == leaf_depth) {
+                if (ok) {
+                    const uint32_t end = first + (1u << star::kLeafBits) < tr.n ? first + (1u << star::kLeafBits) : tr.n;
+                    for (uint32_t k = first; k < end; ++k) try_point(k);
+                }
+                best = wave_min(my_d2);
+                mask[level] = 0;
+            } else {
+                mask[level] = __ballot(ok);
+            }
+            while (mask[level] == 0 && level > 0) --level;
+            if (mask[level] == 0) break;
+            const uint32_t k = (uint32_t)__builtin_ctzll(mask[level]);
+            mask[level] &= mask[level] - 1;
+            base[level + 1] = (base[level] + k) << 6;
+            ++level;
+        }
+    }
+    // the nearest candidate of the wave, the lower index on ties
+    const float d = wave_min(my_d2);
+    const unsigned long long holders = __ballot(my_id != star::kInfinity && my_d2 == d);
+    CoopResult r;
+    r.duplicate = __ballot(duplicate) != 0;
+    r.id = star::kInfinity;
+    r.q[0] = r.q[1] = r.q[2] = 0.0f;
+    if (holders) {
+        const int src = (int)__builtin_ctzll(holders);
+        r.id = __shfl(my_id, src, 64);
+        r.q[0] = __shfl(my_q[0], src, 64);
+        r.q[1] = __shfl(my_q[1], src, 64);
+        r.q[2] = __shfl(my_q[2], src, 64);
+    }
+    return r;
+}
+
+// kCoopWaves waves per second-pass star: that many of its queries run at the same time
+template <int kCoopWaves>
+__global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
+    const float *__restrict__ pts, uint32_t n, const float *__restrict__ tree, uint32_t depth,
+    const uint32_t *__restrict__ seed_adj, const uint32_t *__restrict__ seed_off,
+    const uint32_t *__restrict__ overflow_list, const uint32_t *__restrict__ hull_list, uint32_t hull_count,
+    uint32_t count, const uint32_t *__restrict__ rows, uint32_t *__restrict__ big_rows,
+    uint32_t *__restrict__ degree, StarCounters *__restrict__ counters) {
+    __shared__ BigStar s;
+    __shared__ uint32_t seeds[kBigV];
+    __shared__ int pick[kCoopWaves];
+    __shared__ CoopResult found[kCoopWaves];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     if (w >= count) return;
-    const uint32_t i = overflow_list[first + w];
-    BigStar &s = arena[w];
-    star::star_reset(s, i, pts + 3 * (size_t)i);
-    const uint32_t block_first = i & ~63u;
-    const uint32_t block_count = n - block_first < 64u ? n - block_first : 64u;
-    uint32_t *seeds = big_rows + (size_t)(first + w) * kBigV;   // the result row doubles as the seed list
-    const int ns = gather_seeds<kBigV, kBigT>(pts, n, i, seed_adj, seed_off, pts + 3 * (size_t)block_first,
-                                              block_first, block_count, seeds, kBigV - 1);
+    const uint32_t i = overflow_list[w];
     const star::Tree tr{tree, n, depth};
     uint32_t visited = 0, inserted = 0;
-    star::star_build(s, tr, pts, seeds, ns, visited, inserted);
+    if (tid == 0) {
+        star::star_reset(s, i, pts + 3 * (size_t)i);
+        const uint32_t block_first = i & ~63u;
+        const uint32_t block_count = n - block_first < 64u ? n - block_first : 64u;
+        int ns = (int)degree[i];   // the link vertices the first pass got to
+        if (ns >= 3) {
+            for (int k = 0; k < ns; ++k) seeds[k] = rows[(size_t)i * kSmallV + k];
+        } else {
+            ns = gather_seeds<kBigV, kBigT>(pts, n, i, seed_adj, seed_off, pts + 3 * (size_t)block_first, block_first,
+                                            block_count, seeds, kBigV - 1);
+        }
+        star::star_seed(s, pts, seeds, ns, inserted);
+    }
+    for (;;) {
+        // a round: every wave takes one uncertified triangle; certification is a statement about the whole point
+        // set, so it holds whatever the other waves' answers do to the link afterwards
+        if (tid == 0) {
+            int k = 0;
+            for (int v = 0; v < kCoopWaves; ++v) {
+                pick[v] = -1;
+                if (s.status != star::kOk) continue;
+                while (k < s.nt && (s.tf[k] & star::kCertified)) ++k;
+                if (k < s.nt) pick[v] = k++;
+            }
+        }
+        __syncthreads();
+        if (pick[0] < 0) break;
+        const int t = pick[wave];
+        if (t >= 0) {
+            const CoopResult r = coop_search(s, tr, pts, t, hull_list, hull_count, visited);
+            if ((tid & 63u) == 0) found[wave] = r;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // certifications first (triangle indices are still those of the round), insertions after
+            for (int v = 0; v < kCoopWaves; ++v) {
+                if (pick[v] < 0) continue;
+                if (found[v].duplicate) s.status = star::kDuplicate;
+                else if (found[v].id == star::kInfinity) s.tf[pick[v]] |= star::kCertified;
+            }
+            for (int v = 0; v < kCoopWaves && s.status == star::kOk; ++v) {
+                if (pick[v] < 0 || found[v].id == star::kInfinity) continue;
+                // 0 = the triangle this point conflicted with went with an earlier insertion of the round, and the
+                // point conflicts with nothing that replaced it
+                if (star::star_insert(s, found[v].id, found[v].q) > 0) ++inserted;
+            }
+        }
+        __syncthreads();
+    }
+    if ((tid & 63u) == 0) {
+        const uint32_t old = atomicAdd(&counters->nodes_lo, visited);
+        if (old + visited < old) atomicAdd(&counters->nodes_hi, 1u);
+    }
+    if (tid != 0) return;
+    atomicAdd(&counters->inserted, inserted);
     if (s.status != star::kOk) {
         atomicAdd(&counters->failed[s.status], 1u);
         degree[i] = 0;
         return;
     }
     bool hull;
-    const int deg = star::star_neighbours(s, seeds, 1, &hull);
-    degree[i] = (uint32_t)deg;
-    // the slot is found again through the overflow list position: rows[i][0] keeps it
+    degree[i] = (uint32_t)star::star_neighbours(s, big_rows + (size_t)w * kBigV, 1, &hull);
 }
 
 // rows of the large instance are addressed through rows[i * kSmallV] = position in the overflow list
@@ -332,7 +509,7 @@ static KdLayout kd_layout(uint32_t n) {
 }
 
 struct DelaunayLayout {
-    size_t rows, degree, overflow, counters, big_rows, arena, scan_temp, scan_bytes, total;
+    size_t rows, degree, overflow, hull, counters, big_rows, scan_temp, scan_bytes, total;
     uint32_t arena_stars;
 };
 
@@ -342,8 +519,8 @@ static DelaunayLayout delaunay_layout(uint32_t n) {
     (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)n,
                                   rocprim::plus<uint32_t>(), (hipStream_t)0);
     L.scan_bytes = scan_bytes;
-    // room for one star in 64 in the large instance; a batch loop covers more
-    L.arena_stars = n / 64 < 1024 ? 1024 : n / 64;
+    // result rows of the second pass: room for one star in 32
+    L.arena_stars = n / 32 < 1024 ? 1024 : n / 32;
     size_t at = 0;
     auto take = [&](size_t bytes) {
         const size_t here = at;
@@ -353,9 +530,9 @@ static DelaunayLayout delaunay_layout(uint32_t n) {
     L.rows = take((size_t)n * kSmallV * 4);
     L.degree = take((size_t)n * 4);
     L.overflow = take((size_t)n * 4);
+    L.hull = take((size_t)n * 4);
     L.counters = take(sizeof(StarCounters));
     L.big_rows = take((size_t)L.arena_stars * kBigV * 4);
-    L.arena = take((size_t)L.arena_stars * sizeof(BigStar));
     L.scan_temp = take(scan_bytes);
     L.total = at;
     return L;
@@ -445,13 +622,20 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
     uint32_t *rows = reinterpret_cast<uint32_t *>(base + L.rows);
     uint32_t *degree = reinterpret_cast<uint32_t *>(base + L.degree);
     uint32_t *overflow = reinterpret_cast<uint32_t *>(base + L.overflow);
+    uint32_t *hull = reinterpret_cast<uint32_t *>(base + L.hull);
     StarCounters *counters = reinterpret_cast<StarCounters *>(base + L.counters);
     uint32_t *big_rows = reinterpret_cast<uint32_t *>(base + L.big_rows);
-    BigStar *arena = reinterpret_cast<BigStar *>(base + L.arena);
     const uint32_t depth = tree_depth_of(num_points);
     const uint32_t blocks = (num_points + 63u) / 64u;
 
     if (hipMemsetAsync(counters, 0, sizeof(StarCounters), s) != hipSuccess) return check_launch("rf_delaunay_adjacency");
+    // first pass: a query gets this many tree nodes before its star is parked for the second pass (rf_star.hpp,
+    // HullSet); RF_DELAUNAY_BUDGET=0 disables the parking (tuning / A-B only)
+    static const uint32_t ghost_budget = [] {
+        const char *e = getenv("RF_DELAUNAY_BUDGET");
+        const long v = e ? atol(e) : 512;
+        return v <= 0 ? 0xFFFFFFFFu : (uint32_t)v;
+    }();
     // RF_DELAUNAY_WAVES (4, 6 or 8 waves per SIMD; tuning only): more waves hide more of the tree's load latency,
     // fewer keep more of the star out of scratch
     static const int waves = [] {
@@ -460,7 +644,7 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
     }();
 #define RF_LAUNCH_STARS(W)                                                                                        \
     hipLaunchKernelGGL(delaunay_star_kernel<W>, dim3(blocks), dim3(64), 0, s, points, num_points, aabb_tree, depth, \
-                       seed_adjacency, seed_offsets, rows, degree, overflow, counters)
+                       seed_adjacency, seed_offsets, rows, degree, overflow, hull, ghost_budget, counters)
     if (waves <= 4) RF_LAUNCH_STARS(4);
     else if (waves >= 8) RF_LAUNCH_STARS(8);
     else RF_LAUNCH_STARS(6);
@@ -470,15 +654,28 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
         hipStreamSynchronize(s) != hipSuccess)
         return check_launch("rf_delaunay_adjacency: star kernel");
     if (host.overflow > L.arena_stars) {
-        // more hub stars than the arena holds: not a point cloud this instance is sized for
+        // more second-pass stars than there are rows for: not a point cloud this is sized for
         info[0] = 0; info[1] = host.overflow; info[2] = host.overflow;
-        for (int k = 3; k < 8; ++k) info[k] = 0;
-        return fail(RF_ERR_WORKSPACE, "rf_delaunay_adjacency: more stars need the large instance than its arena holds");
+        for (int k = 3; k < 12; ++k) info[k] = 0;
+        return fail(RF_ERR_WORKSPACE, "rf_delaunay_adjacency: more stars need the second pass than it has rows for");
     }
     if (host.overflow) {
-        hipLaunchKernelGGL(delaunay_star_big_kernel, dim3((host.overflow + 63u) / 64u), dim3(64), 0, s, points,
-                           num_points, aabb_tree, depth, seed_adjacency, seed_offsets, overflow, 0u, host.overflow,
-                           arena, big_rows, degree, counters);
+        // ghost queries of the second pass scan the hull candidates; a cloud with most of its points on its hull (a
+        // sphere shell) keeps the tree instead
+        const bool use_list = host.hull <= 65536u;
+        static const int coop_waves = [] {   // tuning only
+            const char *e = getenv("RF_DELAUNAY_COOP_WAVES");
+            return e ? atoi(e) : 4;
+        }();
+#define RF_LAUNCH_COOP(W)                                                                                            \
+    hipLaunchKernelGGL(delaunay_star_coop_kernel<W>, dim3(host.overflow), dim3(64 * W), 0, s, points, num_points,    \
+                       aabb_tree, depth, seed_adjacency, seed_offsets, overflow,                                     \
+                       use_list ? hull : (const uint32_t *)nullptr, host.hull, host.overflow, rows, big_rows, degree, \
+                       counters)
+        if (coop_waves >= 4) RF_LAUNCH_COOP(4);
+        else if (coop_waves >= 2) RF_LAUNCH_COOP(2);
+        else RF_LAUNCH_COOP(1);
+#undef RF_LAUNCH_COOP
         hipLaunchKernelGGL(mark_big_rows_kernel, dim3((host.overflow + 255u) / 256u), dim3(256), 0, s, overflow,
                            host.overflow, rows);
     }
@@ -495,13 +692,18 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
         hipStreamSynchronize(s) != hipSuccess)
         return check_launch("rf_delaunay_adjacency: assembly");
     info[0] = host.adjacency;
-    info[1] = host.failed[star::kOverflow] + host.failed[star::kDegenerate] + host.failed[star::kBroken];
+    info[1] = host.failed[star::kOverflow] + host.failed[star::kDegenerate] + host.failed[star::kBroken] +
+              host.failed[star::kPending];
     info[2] = host.overflow;
     info[3] = host.failed[star::kDuplicate];
     info[4] = host.asymmetric;
     info[5] = host.nodes_lo;
     info[6] = host.nodes_hi;
     info[7] = host.inserted;
+    info[8] = host.failed[star::kDegenerate];
+    info[9] = host.failed[star::kBroken];
+    info[10] = host.failed[star::kOverflow];
+    info[11] = host.hull;
     return check_launch("rf_delaunay_adjacency");
 }
 

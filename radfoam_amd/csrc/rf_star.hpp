@@ -51,6 +51,23 @@ enum Status : int {
     kDegenerate = 2,   // no non-coplanar starting tetrahedron among the seeds
     kBroken = 3,       // the link stopped being a sphere (cospherical input: the caller perturbs, like the reference)
     kDuplicate = 4,    // another point has the same coordinates
+    kPending = 5,      // a query ran out of budget: the star is redone in the second pass (see HullSet)
+};
+
+// Where the expensive queries go.  Nearly all queries touch a few dozen tree nodes, but a few per thousand stars --
+// those at the rim of the cloud -- ask about regions the tree cannot bound: the half-space behind a facet of the
+// convex hull, or the ball of a flat tetrahedron between rim points, which is so large that it acts like one.  Such a
+// region holds no point, yet the boxes of the tree poke into it all along that side of the cloud: 10^5 nodes for one
+// query, in one lane, while the rest of the launch has long finished.  So the first pass gives every query `budget`
+// tree nodes (a query with a conflicting point nearby finds it within that) and parks the star when a query runs
+// out with nothing found; the second pass (delaunay_star_coop_kernel) gives each parked star a whole wave, the 64
+// lanes testing 64 boxes or points of one query at a time.  There, ghost queries do not use the tree at all: whatever
+// lies beyond a plane, a vertex of the convex hull lies beyond it too, and the hull's vertices are among `ids` -- the
+// points whose first-pass star kept a ghost or did not finish.
+struct HullSet {
+    const uint32_t *ids;   // null in the first pass
+    uint32_t count;
+    uint32_t budget;       // first pass: tree nodes per query (0xFFFFFFFF = unbounded)
 };
 
 enum TriFlag : uint8_t { kCertified = 1, kMarked = 2, kSlow = 4, kGhost = 8 };
@@ -386,17 +403,29 @@ RF_STAR_FN void set_sphere(Star<V, T> &s, int t) {
         const double lc = C.x * C.x + C.y * C.y + C.z * C.z;
         const double pm = (fabs(A.x) + fabs(A.y) + fabs(A.z)) * (fabs(B.x) + fabs(B.y) + fabs(B.z)) *
                           (fabs(C.x) + fabs(C.y) + fabs(C.z));
-        if (det > 1e-7 * pm) {
+        // relative error of the fp64 determinant (and with it of the centre): ~ 8 roundings of 2^-53 over det / pm
+        const double kappa = det > 0 ? 1e-15 * pm / det : 1.0;
+        if (kappa < 0.05) {
             const double h = 0.5 / det;
             const double cx = (la * bc.x + lb * ca.x + lc * ab.x) * h;
             const double cy = (la * bc.y + lb * ca.y + lc * ab.y) * h;
             const double cz = (la * bc.z + lb * ca.z + lc * ab.z) * h;
+            double r2 = cx * cx + cy * cy + cz * cz;
+            if (kappa > 1e-8) {
+                // a sliver: the centre is too vague for the float filter -- every conflict test of this triangle takes
+                // the determinant -- but a ball padded by its uncertainty still bounds the search
+                flags |= kSlow;
+                r2 *= (1.0 + 4.0 * kappa) * (1.0 + 4.0 * kappa);
+            }
             s.sx[t] = (float)cx;
             s.sy[t] = (float)cy;
             s.sz[t] = (float)cz;
-            s.sr[t] = (float)(cx * cx + cy * cy + cz * cz);
-            if (!(s.sr[t] < 3.0e38f)) flags |= kSlow;
-        } else {   // a sliver: the centre is not trustworthy, every test of this triangle takes the determinant
+            s.sr[t] = (float)r2;
+            if (!(s.sr[t] < 3.0e38f)) {
+                flags |= kSlow;
+                s.sr[t] = 3.4e38f;
+            }
+        } else {   // numerically flat: no ball at all
             flags |= kSlow;
             s.sx[t] = s.sy[t] = s.sz[t] = 0.0f;
             s.sr[t] = 3.4e38f;
@@ -559,12 +588,37 @@ RF_STAR_FN float box_dist2(const float *nd, float x, float y, float z) {
 // through the implicit tree, nearer child first, boxes pruned against the triangle's ball (half-space) and against
 // the best candidate so far.  `visited` counts tree nodes (instrumentation).
 template <int V, int T>
-RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts, int t, float *out_q,
-                                uint32_t &visited) {
+RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts, int t, const HullSet &hull,
+                                float *out_q, uint32_t &visited) {
     const uint8_t f = s.tf[t];
     const bool ghost = (f & kGhost) != 0;
-    const bool ball = !ghost && !(f & kSlow);
+    const bool ball = !ghost && s.sr[t] < 3.0e38f;
     const float px = s.p[0], py = s.p[1], pz = s.p[2];
+    const uint32_t g0 = s.vg[s.ta[t]], g1 = s.vg[s.tb[t]], g2 = s.vg[s.tc[t]];
+    if (ghost && hull.ids) {
+        // second pass: whatever lies beyond a plane, a vertex of the convex hull lies beyond it too, and the hull's
+        // vertices are among the few points whose first-pass star kept a ghost
+        float best = 3.4e38f;
+        uint32_t best_id = kInfinity;
+        for (uint32_t h = 0; h < hull.count; ++h) {
+            const uint32_t k = hull.ids[h];
+            if (k == s.self || k == g0 || k == g1 || k == g2) continue;
+            const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
+            const float dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 == 0.0f && q[0] == px && q[1] == py && q[2] == pz) s.status = kDuplicate;
+            if (!(d2 < best) || !conflict(s, t, q)) continue;
+            best = d2;
+            best_id = k;
+            out_q[0] = q[0];
+            out_q[1] = q[1];
+            out_q[2] = q[2];
+        }
+        visited += hull.count;
+        return best_id;
+    }
+    const uint32_t budget = hull.budget;
+    uint32_t spent = 0;
     const float nx = s.sx[t], ny = s.sy[t], nz = s.sz[t];
     // ball in absolute coordinates, radius padded for the roundings of centre and box distance
     const float cx = px + nx, cy = py + ny, cz = pz + nz;
@@ -575,7 +629,6 @@ RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts,
         const float rp = (r + pad) * 1.000002f;
         rp2 = rp * rp;
     }
-    const uint32_t g0 = s.vg[s.ta[t]], g1 = s.vg[s.tb[t]], g2 = s.vg[s.tc[t]];
     const uint32_t leaf_depth = tr.depth - kLeafBits;
     float best = 3.4e38f;
     uint32_t best_id = kInfinity;
@@ -587,6 +640,12 @@ RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts,
         if (first < tr.n) {
             const float *nd = tree_node(tr, depth, idx);
             ++visited;
+            if (++spent > budget) {
+                // out of budget (see HullSet): any conflicting point found so far will do; with none, the star
+                // waits for the second pass
+                if (best_id == kInfinity) s.status = kPending;
+                return best_id;
+            }
             bool ok = box_dist2(nd, px, py, pz) < best;
             if (ok && ball) ok = box_dist2(nd, cx, cy, cz) <= rp2;
             if (ok && ghost && !(f & kSlow)) {
@@ -640,10 +699,9 @@ RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts,
     return best_id;
 }
 
-// Build the star from `nseeds` candidate points (any order; nearest first is cheapest), then certify.
+// First tetrahedron + all the seeds (any order; nearest first is cheapest).
 template <int V, int T>
-RF_STAR_FN void star_build(Star<V, T> &s, const Tree &tr, const float *pts, const uint32_t *seeds, int nseeds,
-                           uint32_t &visited, uint32_t &inserted) {
+RF_STAR_FN void star_seed(Star<V, T> &s, const float *pts, const uint32_t *seeds, int nseeds, uint32_t &inserted) {
     // starting tetrahedron: the first seed triple that is not coplanar with p_i
     int i0 = -1, i1 = -1, i2 = -1;
     for (int a = 0; a < nseeds && i0 < 0; ++a)
@@ -672,6 +730,14 @@ RF_STAR_FN void star_build(Star<V, T> &s, const Tree &tr, const float *pts, cons
         if (star_insert(s, seeds[k], q) < 0) return;
         ++inserted;
     }
+}
+
+// Build the star from `nseeds` candidate points, then certify every triangle.
+template <int V, int T>
+RF_STAR_FN void star_build(Star<V, T> &s, const Tree &tr, const float *pts, const HullSet &hull,
+                           const uint32_t *seeds, int nseeds, uint32_t &visited, uint32_t &inserted) {
+    star_seed(s, pts, seeds, nseeds, inserted);
+    if (s.status != kOk) return;
     for (;;) {
         int t = -1;
         for (int k = 0; k < s.nt; ++k)
@@ -681,7 +747,7 @@ RF_STAR_FN void star_build(Star<V, T> &s, const Tree &tr, const float *pts, cons
             }
         if (t < 0) break;
         float q[3];
-        const uint32_t j = star_search(s, tr, pts, t, q, visited);
+        const uint32_t j = star_search(s, tr, pts, t, hull, q, visited);
         if (s.status != kOk) return;
         if (j == kInfinity) {
             s.tf[t] |= kCertified;

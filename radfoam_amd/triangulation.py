@@ -99,7 +99,7 @@ def delaunay_adjacency(points: torch.Tensor, tree: torch.Tensor | None = None, s
             raise RuntimeError("seed lists must be uint32 tensors of a triangulation of the same number of points")
     ws = torch.empty(max(int(lib.rf_delaunay_workspace_bytes(n)), 256), dtype=torch.uint8, device=dev)
     capacity = 20 * n   # the reference gives up beyond 20 tetrahedra per point (delaunay.cu:352); E ~ 15.5 N
-    info = (C.c_uint32 * 8)()
+    info = (C.c_uint32 * 12)()
     while True:
         adj = torch.empty(capacity, dtype=torch.int32, device=dev)
         off = torch.empty(n + 1, dtype=torch.int32, device=dev)
@@ -112,11 +112,17 @@ def delaunay_adjacency(points: torch.Tensor, tree: torch.Tensor | None = None, s
         capacity = int(info[0])
     stats = dict(adjacency_size=int(info[0]), failed_stars=int(info[1]), large_stars=int(info[2]),
                  duplicate_points=int(info[3]), asymmetric_edges=int(info[4]),
-                 tree_nodes_visited=int(info[5]) | (int(info[6]) << 32), insertions=int(info[7]))
+                 tree_nodes_visited=int(info[5]) | (int(info[6]) << 32), insertions=int(info[7]),
+                 degenerate_stars=int(info[8]), broken_stars=int(info[9]), oversized_stars=int(info[10]),
+                 hull_candidates=int(info[11]))
     if stats["duplicate_points"]:
         raise TriangulationFailedError("duplicate points found")
     if stats["failed_stars"] or stats["asymmetric_edges"]:
-        raise TriangulationFailedError("ambiguous triangulation")
+        raise TriangulationFailedError(
+            "ambiguous triangulation (%d stars failed: %d without a non-coplanar start, %d inconsistent, %d with more "
+            "than 249 neighbours; %d unmatched edges)" % (stats["failed_stars"], stats["degenerate_stars"],
+                                                          stats["broken_stars"], stats["oversized_stars"],
+                                                          stats["asymmetric_edges"]))
     e = stats["adjacency_size"]
     return adj[:e].clone().view(torch.uint32), off.view(torch.uint32), stats
 

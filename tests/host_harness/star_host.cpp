@@ -4,7 +4,9 @@
 // GPU.  Only tests/ loads the library this builds; nothing under radfoam_amd/ does.
 #include <cstdint>
 #include <cstring>
+#include <cstdio>
 #include <vector>
+#include <chrono>
 
 #define RF_STAR_FN static inline
 #define RF_STAR_NOINLINE static __attribute__((noinline))
@@ -13,18 +15,20 @@
 
 using namespace rf::star;
 
-// what delaunay_star_kernel does per lane: seeds = the `knn` nearest points of the lane's 64-point kd-block, or
-// the old neighbour list when one is given
+static uint32_t *g_star_ns = nullptr;   // per-star build time (instrumentation)
+
+// what delaunay_star_kernel / delaunay_star_big_kernel do per lane: seeds = the `knn` nearest points of the lane's
+// 64-point kd-block, or the old neighbour list when one is given
 template <int V, int T>
-static int one_star(const float *pts, uint32_t n, const Tree &tr, uint32_t i, uint32_t knn, const uint32_t *old_adj,
-                    const uint32_t *old_off, uint32_t *row, int stride, uint32_t *degree, uint8_t *hull,
+static int one_star(const float *pts, uint32_t n, const Tree &tr, const HullSet &hull, uint32_t i, uint32_t knn,
+                    const uint32_t *old_adj, const uint32_t *old_off, uint32_t *row, uint32_t *degree, uint8_t *ghost,
                     uint32_t *visited, uint32_t *inserted) {
     static thread_local Star<V, T> s;
     star_reset(s, i, pts + 3 * (size_t)i);
     uint32_t seeds[256];
     int ns = 0;
     if (old_adj) {
-        for (uint32_t e = old_off[i]; e < old_off[i + 1] && ns < 256; ++e) seeds[ns++] = old_adj[e];
+        for (uint32_t e = old_off[i]; e < old_off[i + 1] && ns < V - 1; ++e) seeds[ns++] = old_adj[e];
     } else {
         const uint32_t b0 = i & ~63u, b1 = b0 + 64 < n ? b0 + 64 : n;
         float d2[64];
@@ -42,14 +46,15 @@ static int one_star(const float *pts, uint32_t n, const Tree &tr, uint32_t i, ui
         }
     }
     uint32_t vis = 0, ins = 0;
-    star_build(s, tr, pts, seeds, ns, vis, ins);
-    visited[i] = vis;
-    inserted[i] = ins;
+    const auto t0 = std::chrono::steady_clock::now();
+    star_build(s, tr, pts, hull, seeds, ns, vis, ins);
+    g_star_ns[i] += (uint32_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    visited[i] += vis;
+    inserted[i] += ins;
     if (s.status != kOk) return s.status;
     bool h;
     degree[i] = (uint32_t)star_neighbours(s, row, 1, &h);
-    hull[i] = h;
-    (void)stride;
+    ghost[i] = h;
     return kOk;
 }
 
@@ -62,21 +67,44 @@ int star_host_insphere_sign(const float *p15) { return insphere_sign(p15, p15 + 
 
 int star_host_delaunay(const float *pts, uint32_t n, const float *tree, uint32_t depth, uint32_t knn,
                        const uint32_t *old_adj, const uint32_t *old_off, uint32_t *rows, int stride,
-                       uint32_t *degree, uint8_t *hull, int *status, uint32_t *visited, uint32_t *inserted) {
+                       uint32_t *degree, uint8_t *hull, int *status, uint32_t *visited, uint32_t *inserted,
+                       uint32_t ghost_budget) {
+    if (stride < 250) return -1;
+    static std::vector<uint32_t> ns_store;
+    ns_store.assign(n, 0);
+    g_star_ns = ns_store.data();
     Tree tr{tree, n, depth};
-    int bad = 0;
-#pragma omp parallel for schedule(dynamic, 256) reduction(+ : bad)
+    // first pass: the small instance, ghost queries on a budget
+    const HullSet first{nullptr, 0, ghost_budget};
+#pragma omp parallel for schedule(dynamic, 256)
     for (uint32_t i = 0; i < n; ++i) {
-        int st = stride >= 64 ? one_star<64, 124>(pts, n, tr, i, knn, old_adj, old_off, rows + (size_t)i * stride, stride,
-                                                  degree, hull, visited, inserted)
-                              : kOverflow;
-        if (st == kOverflow && stride >= 250)
-            st = one_star<250, 496>(pts, n, tr, i, knn, old_adj, old_off, rows + (size_t)i * stride, stride, degree,
-                                    hull, visited, inserted);
-        status[i] = st;
-        bad += st != kOk;
+        visited[i] = inserted[i] = 0;
+        hull[i] = 0;
+        status[i] = one_star<64, 124>(pts, n, tr, first, i, knn, old_adj, old_off, rows + (size_t)i * stride, degree,
+                                      hull, visited, inserted);
+    }
+    // hull candidates: stars that kept a ghost or were parked; second pass: the large instance for parked and
+    // overflowing stars, ghost queries through the candidate list
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < n; ++i)
+        if (hull[i] || status[i] != kOk) ids.push_back(i);   // anything not known to be interior
+    const HullSet second{ids.data(), (uint32_t)ids.size(), 0xFFFFFFFFu};
+    int bad = 0;
+    {
+        size_t parked = 0, over = 0;
+        for (uint32_t i = 0; i < n; ++i) parked += status[i] == kPending, over += status[i] == kOverflow;
+        fprintf(stderr, "[star_host] first pass: %zu parked, %zu overflow, %zu hull candidates\n", parked, over, ids.size());
+    }
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : bad)
+    for (uint32_t i = 0; i < n; ++i) {
+        if (status[i] == kPending || status[i] == kOverflow)
+            status[i] = one_star<250, 496>(pts, n, tr, second, i, knn, old_adj, old_off, rows + (size_t)i * stride,
+                                           degree, hull, visited, inserted);
+        bad += status[i] != kOk;
     }
     return bad;
 }
+
+const uint32_t *star_host_times() { return g_star_ns; }
 
 }  // extern "C"

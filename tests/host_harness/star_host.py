@@ -36,7 +36,7 @@ def lib():
         _lib.star_host_delaunay.restype = C.c_int
         _lib.star_host_delaunay.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.c_void_p, C.c_void_p]
+                                            C.c_void_p, C.c_void_p, C.c_uint32]
     return _lib
 
 
@@ -64,7 +64,7 @@ def aabb_tree(points: np.ndarray) -> np.ndarray:
     return tree
 
 
-def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250):
+def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250, ghost_budget: int = 2048):
     """(offsets, adjacency, info) through the host build of the star code."""
     pts = np.ascontiguousarray(points, dtype=np.float32)
     n = pts.shape[0]
@@ -83,7 +83,7 @@ def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250):
     bad = lib().star_host_delaunay(pts.ctypes.data, n, tree.ctypes.data, depth, knn,
                                    None if oa is None else oa.ctypes.data, None if oo is None else oo.ctypes.data,
                                    rows.ctypes.data, stride, degree.ctypes.data, hull.ctypes.data,
-                                   status.ctypes.data, visited.ctypes.data, inserted.ctypes.data)
+                                   status.ctypes.data, visited.ctypes.data, inserted.ctypes.data, ghost_budget)
     offsets = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(degree, out=offsets[1:])
     mask = np.arange(stride)[None, :] < degree[:, None]

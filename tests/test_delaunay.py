@@ -193,6 +193,17 @@ def test_gpu_stars_on_the_cached_foams():
         assert np.array_equal(off.cpu().numpy(), fm["point_adjacency_offsets"]), n
         assert np.array_equal(adj.cpu().numpy(), fm["point_adjacency"]), n
         assert stats["asymmetric_edges"] == 0 and stats["failed_stars"] == 0
+        assert stats["large_stars"] > 0   # the rim of the cloud went through the second pass
+        # an optimiser step later (3 % of the spacing): the previous lists as candidates give the lists a fresh build
+        # of the moved points gives (the second pass must see every hull candidate for that: stars that outgrew the
+        # small instance included)
+        g = torch.Generator("cuda").manual_seed(n)
+        moved = pts + 0.03 * (8.0 / n) ** (1 / 3) * torch.randn(pts.shape, device="cuda", generator=g)
+        adj1, off1, _ = triangulation.delaunay_adjacency(moved, seed=(adj, off))
+        adj2, off2, _ = triangulation.delaunay_adjacency(moved)
+        assert torch.equal(adj1.view(torch.int32), adj2.view(torch.int32))
+        assert torch.equal(off1.view(torch.int32), off2.view(torch.int32))
+        assert not torch.equal(off1.view(torch.int32), off.view(torch.int32))
 
 
 @pytest.mark.gpu
