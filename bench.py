@@ -238,7 +238,21 @@ def main():
     cache = foam.default_cache_dir()
     if world > 1 and rank != 0:
         dist.barrier()      # rank 0 triangulates (or loads) first, so the cache is written once
-    fm = foam.make_synthetic_foam(W["points"], sh_degree, W["seed"], cache_dir=cache)
+    tri_ms = {}
+
+    def gpu_triangulation(raw):
+        # no cached Qhull lists for this foam (a fresh clone): the GPU triangulation builds them in under a second
+        # instead of minutes of Qhull; tests/test_delaunay.py holds its lists equal to Qhull's on the cached foams
+        from radfoam_amd import triangulation
+        t0 = time.perf_counter()
+        _, sorted_pts = triangulation.kd_order(torch.from_numpy(raw).to(dev))
+        adj, off, _ = triangulation.delaunay_adjacency(sorted_pts)
+        torch.cuda.synchronize(dev)
+        tri_ms["triangulation_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+        return sorted_pts.cpu().numpy(), off.cpu().numpy(), adj.cpu().numpy()
+
+    fm = foam.make_synthetic_foam(W["points"], sh_degree, W["seed"], cache_dir=cache,
+                                  triangulate=gpu_triangulation if dev.type == "cuda" else None)
     if world > 1 and rank == 0:
         dist.barrier()
     attr_dtype = torch.float16 if W["kind"] == "render" else torch.float32
@@ -395,7 +409,8 @@ def main():
 
     # ---- untimed extras: exact walk counters, compulsory-traffic floor, full pack -----------------
     detail = {"forward_ms": round(fwd_ms, 4), "backward_ms": round(bwd_ms, 4), "foam_pack_ms": round(pack_ms, 4),
-              "setup_seconds": round(setup_s, 1)}
+              "setup_seconds": round(setup_s, 1), "foam_csr": fm["csr_source"]}
+    detail.update(tri_ms)
     if world > 1:
         detail["exchange_ms"] = round(exch_ms, 4)
         detail["per_rank_ms_fwd_bwd_exchange_pack"] = rank_ms

@@ -81,7 +81,7 @@ def nearest_point(points: np.ndarray, query: np.ndarray) -> int:
 
 
 def make_synthetic_foam(n_points: int, sh_degree: int, seed: int, *, shell_radius: float = 0.8,
-                        optical_depth_per_cell: float = 0.15, cache_dir: str | None = None):
+                        optical_depth_per_cell: float = 0.15, cache_dir: str | None = None, triangulate=None):
     """Seeded synthetic foam, SURVEY.md section 8(d) recipe.
 
     points ~ U[-1,1]^3 in kd-order; density (already activated) = sigma0*U[0.5,1.5] with
@@ -91,13 +91,22 @@ def make_synthetic_foam(n_points: int, sh_degree: int, seed: int, *, shell_radiu
 
     ``cache_dir``: if given, the slow Qhull step (kd-ordered points + CSR, which do not
     depend on sh_degree) is cached there as an .npz.
+    ``triangulate``: optional ``points -> (kd-ordered points, offsets, adjacency)`` used instead of
+    kd_order + Qhull when nothing is cached (bench.py passes the GPU triangulation, whose lists the GPU
+    tests hold equal to Qhull's on these very foams); the result is then not written to the cache, which
+    stays a Qhull artefact.  ``foam["csr_source"]`` says where the lists came from.
     """
     rng = np.random.default_rng(seed)
     pts = rng.uniform(-1.0, 1.0, size=(n_points, 3)).astype(np.float32)
     path = None if cache_dir is None else os.path.join(cache_dir, f"foam_n{n_points}_s{seed}.npz")
+    source = "qhull"
     if path is not None and os.path.exists(path):
         z = np.load(path)
         pts, offsets, adjacency = z["points"], z["offsets"], z["adjacency"]
+        source = "qhull (cached)"
+    elif triangulate is not None:
+        pts, offsets, adjacency = triangulate(pts)
+        source = "gpu"
     else:
         pts = np.ascontiguousarray(pts[kd_order(pts)])
         offsets, adjacency = delaunay_csr(pts)
@@ -123,6 +132,7 @@ def make_synthetic_foam(n_points: int, sh_degree: int, seed: int, *, shell_radiu
         "point_adjacency_offsets": offsets,
         "sh_degree": sh_degree,
         "seed": seed,
+        "csr_source": source,
     }
 
 
