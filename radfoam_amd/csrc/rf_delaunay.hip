@@ -135,15 +135,14 @@ __device__ __forceinline__ int gather_seeds(const float *__restrict__ pts, uint3
     return ns;
 }
 
+// First pass: one lane per point, a wave = 64 consecutive points of the kd-order; the lane's star is a private
+// (scratch) record.
 template <int WAVES_PER_SIMD>
-__global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(const float *__restrict__ pts, uint32_t n,
-                                                           const float *__restrict__ tree, uint32_t depth,
-                                                           const uint32_t *__restrict__ seed_adj,
-                                                           const uint32_t *__restrict__ seed_off,
-                                                           uint32_t *__restrict__ rows, uint32_t *__restrict__ degree,
-                                                           uint32_t *__restrict__ overflow_list,
-                                                           uint32_t *__restrict__ hull_list, uint32_t ghost_budget,
-                                                           StarCounters *__restrict__ counters) {
+__global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(
+    const float *__restrict__ pts, uint32_t n, const float *__restrict__ tree, uint32_t depth,
+    const uint32_t *__restrict__ seed_adj, const uint32_t *__restrict__ seed_off, uint32_t *__restrict__ rows,
+    uint32_t *__restrict__ degree, uint32_t *__restrict__ overflow_list, uint32_t *__restrict__ hull_list,
+    uint32_t budget, StarCounters *__restrict__ counters) {
     __shared__ float block_pts[64 * 3];
     const uint32_t block_first = blockIdx.x * 64u;
     const uint32_t block_count = n - block_first < 64u ? n - block_first : 64u;
@@ -158,21 +157,21 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(const
     const int ns = gather_seeds<kSmallV, kSmallT>(pts, n, i, seed_adj, seed_off, block_pts, block_first, block_count,
                                                   seeds, kSmallV - 1);
     const star::Tree tr{tree, n, depth};
+    const star::HullSet first_pass{nullptr, 0u, budget};
     uint32_t visited = 0, inserted = 0;
-    const star::HullSet first_pass{nullptr, 0u, ghost_budget};
     star::star_build(s, tr, pts, first_pass, seeds, ns, visited, inserted);
     atomicAdd(&counters->inserted, inserted);
     const uint32_t old = atomicAdd(&counters->nodes_lo, visited);
     if (old + visited < old) atomicAdd(&counters->nodes_hi, 1u);
 
+    uint32_t *row = rows + (size_t)i * kSmallV;
     if (s.status == star::kOverflow || s.status == star::kPending) {
         overflow_list[atomicAdd(&counters->overflow, 1u)] = i;
         hull_list[atomicAdd(&counters->hull, 1u)] = i;   // not known to be interior: a hull candidate
         // what this pass found so far are the second pass's first candidates
-        uint32_t *row = rows + (size_t)i * kSmallV;
         uint32_t c = 0;
         for (int k = 1; k < kSmallV; ++k)
-            if (s.vuse[k]) row[c++] = s.vg[k];
+            if (s.v[k].use) row[c++] = s.v[k].g;
         degree[i] = c;
         return;
     }
@@ -182,11 +181,8 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(const
         return;
     }
     bool hull;
-    uint32_t nb[kSmallV];
-    const int deg = star::star_neighbours(s, nb, 1, &hull);
+    const int deg = star::star_neighbours(s, row, 1, &hull);   // ascending, straight into the row
     if (hull) hull_list[atomicAdd(&counters->hull, 1u)] = i;   // a vertex of the convex hull
-    uint32_t *row = rows + (size_t)i * kSmallV;
-    for (int k = 0; k < deg; ++k) row[k] = nb[k];
     degree[i] = (uint32_t)deg;
 }
 
@@ -212,20 +208,20 @@ struct CoopResult {
 __device__ CoopResult coop_search(const BigStar &s, const star::Tree &tr, const float *__restrict__ pts, int t,
                                   const uint32_t *__restrict__ hull_ids, uint32_t hull_count, uint32_t &visited) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint8_t f = s.tf[t];
+    const uint8_t f = s.t[t].f;
     const bool ghost = (f & star::kGhost) != 0;
-    const bool ball = !ghost && s.sr[t] < 3.0e38f;
+    const bool ball = !ghost && s.t[t].sr < 3.0e38f;
     const float px = s.p[0], py = s.p[1], pz = s.p[2];
-    const float nx = s.sx[t], ny = s.sy[t], nz = s.sz[t];
+    const float nx = s.t[t].sx, ny = s.t[t].sy, nz = s.t[t].sz;
     const float cx = px + nx, cy = py + ny, cz = pz + nz;
     float rp2 = 3.4e38f;
     if (ball) {
-        const float r = sqrtf(s.sr[t]);
+        const float r = sqrtf(s.t[t].sr);
         const float pad = 4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(nx) + fabsf(ny) + fabsf(nz) + r);
         const float rp = (r + pad) * 1.000002f;
         rp2 = rp * rp;
     }
-    const uint32_t g0 = s.vg[s.ta[t]], g1 = s.vg[s.tb[t]], g2 = s.vg[s.tc[t]];
+    const uint32_t g0 = s.v[s.t[t].a].g, g1 = s.v[s.t[t].b].g, g2 = s.v[s.t[t].c].g;
     float best = 3.4e38f;        // wave-uniform: prunes
     float my_d2 = 3.4e38f;       // this lane's candidate
     uint32_t my_id = star::kInfinity;
@@ -348,7 +344,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
             for (int v = 0; v < kCoopWaves; ++v) {
                 pick[v] = -1;
                 if (s.status != star::kOk) continue;
-                while (k < s.nt && (s.tf[k] & star::kCertified)) ++k;
+                while (k < s.nt && (s.t[k].f & star::kCertified)) ++k;
                 if (k < s.nt) pick[v] = k++;
             }
         }
@@ -365,7 +361,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
             for (int v = 0; v < kCoopWaves; ++v) {
                 if (pick[v] < 0) continue;
                 if (found[v].duplicate) s.status = star::kDuplicate;
-                else if (found[v].id == star::kInfinity) s.tf[pick[v]] |= star::kCertified;
+                else if (found[v].id == star::kInfinity) s.t[pick[v]].f |= star::kCertified;
             }
             for (int v = 0; v < kCoopWaves && s.status == star::kOk; ++v) {
                 if (pick[v] < 0 || found[v].id == star::kInfinity) continue;
@@ -636,8 +632,7 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
         const long v = e ? atol(e) : 512;
         return v <= 0 ? 0xFFFFFFFFu : (uint32_t)v;
     }();
-    // RF_DELAUNAY_WAVES (4, 6 or 8 waves per SIMD; tuning only): more waves hide more of the tree's load latency,
-    // fewer keep more of the star out of scratch
+    // RF_DELAUNAY_WAVES (4, 6 or 8 waves per SIMD; tuning only)
     static const int waves = [] {
         const char *e = getenv("RF_DELAUNAY_WAVES");
         return e ? atoi(e) : 6;

@@ -317,6 +317,18 @@ RF_STAR_FN int insphere_sign(const float *pi, const float *pa, const float *pb, 
 
 // ---- the star -------------------------------------------------------------------------------------------------------
 
+// One record per link vertex / link triangle.
+struct Vert {
+    uint32_t g;      // global id; slot 0 of a star is the point at infinity
+    float x, y, z;
+    uint32_t use;    // triangles using the slot; 0 = free
+};
+
+struct Tri {
+    uint8_t a, b, c, f;    // link triangle (a,b,c) with det[a-i; b-i; c-i] > 0; f = TriFlag bits
+    float sx, sy, sz, sr;  // finite: circumcentre relative to p_i and squared radius; ghost: outward normal of the facet
+};
+
 template <int V, int T>
 struct Star {
     static constexpr int kV = V, kT = T;
@@ -324,14 +336,8 @@ struct Star {
     int status;
     int nt;
     float p[3];
-    // link vertices; slot 0 is the point at infinity
-    uint32_t vg[V];
-    float vx[V], vy[V], vz[V];
-    uint16_t vuse[V];   // triangles using the slot; 0 = free
-    // link triangles (a,b,c), det[a-i; b-i; c-i] > 0
-    uint8_t ta[T], tb[T], tc[T], tf[T];
-    // finite: circumcentre relative to p_i and squared radius; ghost: normal of the facet plane (pointing outwards)
-    float sx[T], sy[T], sz[T], sr[T];
+    Vert v[V];
+    Tri t[T];
 };
 
 template <int V, int T>
@@ -342,22 +348,22 @@ RF_STAR_FN void star_reset(Star<V, T> &s, uint32_t self, const float *p) {
     s.p[0] = p[0];
     s.p[1] = p[1];
     s.p[2] = p[2];
-    for (int k = 0; k < V; ++k) s.vuse[k] = 0;
-    s.vg[0] = kInfinity;
-    s.vx[0] = s.vy[0] = s.vz[0] = 0.0f;
+    for (int k = 0; k < V; ++k) s.v[k].use = 0;
+    s.v[0].g = kInfinity;
+    s.v[0].x = s.v[0].y = s.v[0].z = 0.0f;
 }
 
 template <int V, int T>
 RF_STAR_FN void vertex_xyz(const Star<V, T> &s, int slot, float *out) {
-    out[0] = s.vx[slot];
-    out[1] = s.vy[slot];
-    out[2] = s.vz[slot];
+    out[0] = s.v[slot].x;
+    out[1] = s.v[slot].y;
+    out[2] = s.v[slot].z;
 }
 
 // the two finite vertices (u, v) of a ghost triangle, rotated so that infinity comes last
 template <int V, int T>
 RF_STAR_FN void ghost_edge(const Star<V, T> &s, int t, int &u, int &v) {
-    const int a = s.ta[t], b = s.tb[t], c = s.tc[t];
+    const int a = s.t[t].a, b = s.t[t].b, c = s.t[t].c;
     if (c == 0) {
         u = a;
         v = b;
@@ -372,13 +378,13 @@ RF_STAR_FN void ghost_edge(const Star<V, T> &s, int t, int &u, int &v) {
 
 template <int V, int T>
 RF_STAR_FN void set_sphere(Star<V, T> &s, int t) {
-    const int a = s.ta[t], b = s.tb[t], c = s.tc[t];
+    const int a = s.t[t].a, b = s.t[t].b, c = s.t[t].c;
     uint8_t flags = 0;
     if (a == 0 || b == 0 || c == 0) {
         int u, v;
         ghost_edge(s, t, u, v);
-        const D3 A = diff(s.vx[u], s.vy[u], s.vz[u], s.p[0], s.p[1], s.p[2]);
-        const D3 B = diff(s.vx[v], s.vy[v], s.vz[v], s.p[0], s.p[1], s.p[2]);
+        const D3 A = diff(s.v[u].x, s.v[u].y, s.v[u].z, s.p[0], s.p[1], s.p[2]);
+        const D3 B = diff(s.v[v].x, s.v[v].y, s.v[v].z, s.p[0], s.p[1], s.p[2]);
         const double nx = A.y * B.z - A.z * B.y, ny = A.z * B.x - A.x * B.z, nz = A.x * B.y - A.y * B.x;
         const double nm = fmax(fabs(nx), fmax(fabs(ny), fabs(nz)));
         const double am = fmax(fabs(A.x), fmax(fabs(A.y), fabs(A.z)));
@@ -387,14 +393,14 @@ RF_STAR_FN void set_sphere(Star<V, T> &s, int t) {
         if (!(nm > 1e-6 * am * bm)) flags |= kSlow;   // i, u, v nearly collinear: the float normal means nothing
         // scale does not matter for a half-space: keep the normal in float range
         const double sc = nm > 0 ? 1.0 / nm : 0.0;
-        s.sx[t] = (float)(nx * sc);
-        s.sy[t] = (float)(ny * sc);
-        s.sz[t] = (float)(nz * sc);
-        s.sr[t] = -1.0f;
+        s.t[t].sx = (float)(nx * sc);
+        s.t[t].sy = (float)(ny * sc);
+        s.t[t].sz = (float)(nz * sc);
+        s.t[t].sr = -1.0f;
     } else {
-        const D3 A = diff(s.vx[a], s.vy[a], s.vz[a], s.p[0], s.p[1], s.p[2]);
-        const D3 B = diff(s.vx[b], s.vy[b], s.vz[b], s.p[0], s.p[1], s.p[2]);
-        const D3 C = diff(s.vx[c], s.vy[c], s.vz[c], s.p[0], s.p[1], s.p[2]);
+        const D3 A = diff(s.v[a].x, s.v[a].y, s.v[a].z, s.p[0], s.p[1], s.p[2]);
+        const D3 B = diff(s.v[b].x, s.v[b].y, s.v[b].z, s.p[0], s.p[1], s.p[2]);
+        const D3 C = diff(s.v[c].x, s.v[c].y, s.v[c].z, s.p[0], s.p[1], s.p[2]);
         const D3 bc{B.y * C.z - B.z * C.y, B.z * C.x - B.x * C.z, B.x * C.y - B.y * C.x};
         const D3 ca{C.y * A.z - C.z * A.y, C.z * A.x - C.x * A.z, C.x * A.y - C.y * A.x};
         const D3 ab{A.y * B.z - A.z * B.y, A.z * B.x - A.x * B.z, A.x * B.y - A.y * B.x};
@@ -417,31 +423,31 @@ RF_STAR_FN void set_sphere(Star<V, T> &s, int t) {
                 flags |= kSlow;
                 r2 *= (1.0 + 4.0 * kappa) * (1.0 + 4.0 * kappa);
             }
-            s.sx[t] = (float)cx;
-            s.sy[t] = (float)cy;
-            s.sz[t] = (float)cz;
-            s.sr[t] = (float)r2;
-            if (!(s.sr[t] < 3.0e38f)) {
+            s.t[t].sx = (float)cx;
+            s.t[t].sy = (float)cy;
+            s.t[t].sz = (float)cz;
+            s.t[t].sr = (float)r2;
+            if (!(s.t[t].sr < 3.0e38f)) {
                 flags |= kSlow;
-                s.sr[t] = 3.4e38f;
+                s.t[t].sr = 3.4e38f;
             }
         } else {   // numerically flat: no ball at all
             flags |= kSlow;
-            s.sx[t] = s.sy[t] = s.sz[t] = 0.0f;
-            s.sr[t] = 3.4e38f;
+            s.t[t].sx = s.t[t].sy = s.t[t].sz = 0.0f;
+            s.t[t].sr = 3.4e38f;
         }
     }
-    s.tf[t] = flags;
+    s.t[t].f = flags;
 }
 
 // does the point q (global coordinates) conflict with triangle t?  Exact.
 template <int V, int T>
 RF_STAR_FN bool conflict(const Star<V, T> &s, int t, const float *q) {
     const float qx = q[0] - s.p[0], qy = q[1] - s.p[1], qz = q[2] - s.p[2];
-    const uint8_t f = s.tf[t];
+    const uint8_t f = s.t[t].f;
     if (f & kGhost) {
         if (!(f & kSlow)) {
-            const float tx = s.sx[t] * qx, ty = s.sy[t] * qy, tz = s.sz[t] * qz;
+            const float tx = s.t[t].sx * qx, ty = s.t[t].sy * qy, tz = s.t[t].sz * qz;
             const float d = tx + ty + tz;
             const float u = 4e-6f * (fabsf(tx) + fabsf(ty) + fabsf(tz)) + 1e-37f;
             if (d > u) return true;
@@ -455,22 +461,22 @@ RF_STAR_FN bool conflict(const Star<V, T> &s, int t, const float *q) {
         return orient_sign(s.p, pa, pb, q) > 0;
     }
     if (!(f & kSlow)) {
-        const float dx = qx - s.sx[t], dy = qy - s.sy[t], dz = qz - s.sz[t];
-        const float d2 = dx * dx + dy * dy + dz * dz, r2 = s.sr[t];
+        const float dx = qx - s.t[t].sx, dy = qy - s.t[t].sy, dz = qz - s.t[t].sz;
+        const float d2 = dx * dx + dy * dy + dz * dz, r2 = s.t[t].sr;
         const float u = 4e-6f * (d2 + r2) + 1e-37f;
         if (d2 > r2 + u) return false;
         if (d2 < r2 - u) return true;
     }
     float pa[3], pb[3], pc[3];
-    vertex_xyz(s, s.ta[t], pa);
-    vertex_xyz(s, s.tb[t], pb);
-    vertex_xyz(s, s.tc[t], pc);
+    vertex_xyz(s, s.t[t].a, pa);
+    vertex_xyz(s, s.t[t].b, pb);
+    vertex_xyz(s, s.t[t].c, pc);
     return insphere_sign(s.p, pa, pb, pc, q) < 0;
 }
 
 template <int V, int T>
 RF_STAR_FN bool has_directed_edge(const Star<V, T> &s, int t, int u, int v) {
-    const int a = s.ta[t], b = s.tb[t], c = s.tc[t];
+    const int a = s.t[t].a, b = s.t[t].b, c = s.t[t].c;
     return (a == u && b == v) || (b == u && c == v) || (c == u && a == v);
 }
 
@@ -481,22 +487,22 @@ RF_STAR_FN bool star_init(Star<V, T> &s, uint32_t ga, const float *pa, uint32_t 
     const int o = orient_sign(s.p, pa, pb, pc);
     if (o == 0) return false;
     const float *q1 = o > 0 ? pa : pb, *q2 = o > 0 ? pb : pa;
-    s.vg[1] = o > 0 ? ga : gb;
-    s.vg[2] = o > 0 ? gb : ga;
-    s.vg[3] = gc;
-    s.vx[1] = q1[0]; s.vy[1] = q1[1]; s.vz[1] = q1[2];
-    s.vx[2] = q2[0]; s.vy[2] = q2[1]; s.vz[2] = q2[2];
-    s.vx[3] = pc[0]; s.vy[3] = pc[1]; s.vz[3] = pc[2];
+    s.v[1].g = o > 0 ? ga : gb;
+    s.v[2].g = o > 0 ? gb : ga;
+    s.v[3].g = gc;
+    s.v[1].x = q1[0]; s.v[1].y = q1[1]; s.v[1].z = q1[2];
+    s.v[2].x = q2[0]; s.v[2].y = q2[1]; s.v[2].z = q2[2];
+    s.v[3].x = pc[0]; s.v[3].y = pc[1]; s.v[3].z = pc[2];
     // (1,2,3), (2,1,inf), (3,2,inf), (1,3,inf): every directed edge once, its reverse once
     const uint8_t tri[4][3] = {{1, 2, 3}, {2, 1, 0}, {3, 2, 0}, {1, 3, 0}};
     for (int t = 0; t < 4; ++t) {
-        s.ta[t] = tri[t][0];
-        s.tb[t] = tri[t][1];
-        s.tc[t] = tri[t][2];
+        s.t[t].a = tri[t][0];
+        s.t[t].b = tri[t][1];
+        s.t[t].c = tri[t][2];
     }
     s.nt = 4;
-    s.vuse[0] = 3;
-    s.vuse[1] = s.vuse[2] = s.vuse[3] = 3;
+    s.v[0].use = 3;
+    s.v[1].use = s.v[2].use = s.v[3].use = 3;
     for (int t = 0; t < 4; ++t) set_sphere(s, t);
     return true;
 }
@@ -508,13 +514,13 @@ RF_STAR_FN int star_insert(Star<V, T> &s, uint32_t gq, const float *q) {
     int marked = 0;
     for (int t = 0; t < nt0; ++t)
         if (conflict(s, t, q)) {
-            s.tf[t] |= kMarked;
+            s.t[t].f |= kMarked;
             ++marked;
         }
     if (marked == 0) return 0;
     int slot = -1;
     for (int k = 1; k < V; ++k)
-        if (s.vuse[k] == 0) {
+        if (s.v[k].use == 0) {
             slot = k;
             break;
         }
@@ -522,32 +528,32 @@ RF_STAR_FN int star_insert(Star<V, T> &s, uint32_t gq, const float *q) {
         s.status = kOverflow;
         return -1;
     }
-    s.vg[slot] = gq;
-    s.vx[slot] = q[0];
-    s.vy[slot] = q[1];
-    s.vz[slot] = q[2];
+    s.v[slot].g = gq;
+    s.v[slot].x = q[0];
+    s.v[slot].y = q[1];
+    s.v[slot].z = q[2];
     // every directed edge of the hole whose reverse is not in the hole lies on its boundary: fan it to q
     int nt = nt0;
     for (int t = 0; t < nt0; ++t) {
-        if (!(s.tf[t] & kMarked)) continue;
-        const int v3[4] = {s.ta[t], s.tb[t], s.tc[t], s.ta[t]};
+        if (!(s.t[t].f & kMarked)) continue;
+        const int v3[4] = {s.t[t].a, s.t[t].b, s.t[t].c, s.t[t].a};
         for (int e = 0; e < 3; ++e) {
             const int u = v3[e], v = v3[e + 1];
             bool inner = false;
             for (int t2 = 0; t2 < nt0 && !inner; ++t2)
-                inner = (s.tf[t2] & kMarked) && t2 != t && has_directed_edge(s, t2, v, u);
+                inner = (s.t[t2].f & kMarked) && t2 != t && has_directed_edge(s, t2, v, u);
             if (inner) continue;
             if (nt >= T) {
                 s.status = kOverflow;
                 return -1;
             }
-            s.ta[nt] = (uint8_t)u;
-            s.tb[nt] = (uint8_t)v;
-            s.tc[nt] = (uint8_t)slot;
-            s.tf[nt] = 0;
-            ++s.vuse[u];
-            ++s.vuse[v];
-            ++s.vuse[slot];
+            s.t[nt].a = (uint8_t)u;
+            s.t[nt].b = (uint8_t)v;
+            s.t[nt].c = (uint8_t)slot;
+            s.t[nt].f = 0;
+            ++s.v[u].use;
+            ++s.v[v].use;
+            ++s.v[slot].use;
             ++nt;
         }
     }
@@ -557,16 +563,13 @@ RF_STAR_FN int star_insert(Star<V, T> &s, uint32_t gq, const float *q) {
     int vanished = 0;   // link vertices that were interior to the hole
     int t = 0;
     while (t < nt) {
-        if (!(s.tf[t] & kMarked)) {
+        if (!(s.t[t].f & kMarked)) {
             ++t;
             continue;
         }
-        vanished += (--s.vuse[s.ta[t]] == 0) + (--s.vuse[s.tb[t]] == 0) + (--s.vuse[s.tc[t]] == 0);
+        vanished += (--s.v[s.t[t].a].use == 0) + (--s.v[s.t[t].b].use == 0) + (--s.v[s.t[t].c].use == 0);
         --nt;
-        if (t != nt) {
-            s.ta[t] = s.ta[nt]; s.tb[t] = s.tb[nt]; s.tc[t] = s.tc[nt]; s.tf[t] = s.tf[nt];
-            s.sx[t] = s.sx[nt]; s.sy[t] = s.sy[nt]; s.sz[t] = s.sz[nt]; s.sr[t] = s.sr[nt];
-        }
+        if (t != nt) s.t[t] = s.t[nt];
     }
     s.nt = nt;
     // a hole that is a disc of m triangles around k interior vertices has m + 2 - 2k boundary edges
@@ -590,11 +593,11 @@ RF_STAR_FN float box_dist2(const float *nd, float x, float y, float z) {
 template <int V, int T>
 RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts, int t, const HullSet &hull,
                                 float *out_q, uint32_t &visited) {
-    const uint8_t f = s.tf[t];
+    const uint8_t f = s.t[t].f;
     const bool ghost = (f & kGhost) != 0;
-    const bool ball = !ghost && s.sr[t] < 3.0e38f;
+    const bool ball = !ghost && s.t[t].sr < 3.0e38f;
     const float px = s.p[0], py = s.p[1], pz = s.p[2];
-    const uint32_t g0 = s.vg[s.ta[t]], g1 = s.vg[s.tb[t]], g2 = s.vg[s.tc[t]];
+    const uint32_t g0 = s.v[s.t[t].a].g, g1 = s.v[s.t[t].b].g, g2 = s.v[s.t[t].c].g;
     if (ghost && hull.ids) {
         // second pass: whatever lies beyond a plane, a vertex of the convex hull lies beyond it too, and the hull's
         // vertices are among the few points whose first-pass star kept a ghost
@@ -619,12 +622,13 @@ RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts,
     }
     const uint32_t budget = hull.budget;
     uint32_t spent = 0;
-    const float nx = s.sx[t], ny = s.sy[t], nz = s.sz[t];
+    const float nx = s.t[t].sx, ny = s.t[t].sy, nz = s.t[t].sz;
     // ball in absolute coordinates, radius padded for the roundings of centre and box distance
     const float cx = px + nx, cy = py + ny, cz = pz + nz;
     float rp2 = 3.4e38f;
+    const float s_r2 = s.t[t].sr;
     if (ball) {
-        const float r = sqrtf(s.sr[t]);
+        const float r = sqrtf(s_r2);
         const float pad = 4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(nx) + fabsf(ny) + fabsf(nz) + r);
         const float rp = (r + pad) * 1.000002f;
         rp2 = rp * rp;
@@ -667,7 +671,17 @@ RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts,
                         const float d2 = dx * dx + dy * dy + dz * dz;
                         if (d2 == 0.0f && q[0] == px && q[1] == py && q[2] == pz) s.status = kDuplicate;
                         if (!(d2 < best)) continue;
-                        if (!conflict(s, t, q)) continue;
+                        // the float filter of conflict(), from the copy of the sphere this walk holds in registers
+                        // (the star lives in scratch: every lane asks about another triangle here, and a scattered
+                        // scratch read costs a cache line per dword)
+                        if (ball && !(f & kSlow)) {
+                            const float ex = dx - nx, ey = dy - ny, ez = dz - nz;
+                            const float e2 = ex * ex + ey * ey + ez * ez, r2 = s_r2;
+                            if (e2 > r2 + 4e-6f * (e2 + r2) + 1e-37f) continue;
+                            if (!(e2 < r2 - (4e-6f * (e2 + r2) + 1e-37f)) && !conflict(s, t, q)) continue;
+                        } else if (!conflict(s, t, q)) {
+                            continue;
+                        }
                         best = d2;
                         best_id = k;
                         out_q[0] = q[0];
@@ -741,7 +755,7 @@ RF_STAR_FN void star_build(Star<V, T> &s, const Tree &tr, const float *pts, cons
     for (;;) {
         int t = -1;
         for (int k = 0; k < s.nt; ++k)
-            if (!(s.tf[k] & kCertified)) {
+            if (!(s.t[k].f & kCertified)) {
                 t = k;
                 break;
             }
@@ -750,7 +764,7 @@ RF_STAR_FN void star_build(Star<V, T> &s, const Tree &tr, const float *pts, cons
         const uint32_t j = star_search(s, tr, pts, t, hull, q, visited);
         if (s.status != kOk) return;
         if (j == kInfinity) {
-            s.tf[t] |= kCertified;
+            s.t[t].f |= kCertified;
             continue;
         }
         if (star_insert(s, j, q) <= 0) {
@@ -766,8 +780,8 @@ template <int V, int T>
 RF_STAR_FN int star_neighbours(const Star<V, T> &s, uint32_t *out, int stride, bool *hull) {
     int n = 0;
     for (int k = 1; k < V; ++k) {
-        if (s.vuse[k] == 0) continue;
-        const uint32_t g = s.vg[k];
+        if (s.v[k].use == 0) continue;
+        const uint32_t g = s.v[k].g;
         int pos = n;
         while (pos > 0 && out[(size_t)(pos - 1) * stride] > g) {
             out[(size_t)pos * stride] = out[(size_t)(pos - 1) * stride];
@@ -776,7 +790,7 @@ RF_STAR_FN int star_neighbours(const Star<V, T> &s, uint32_t *out, int stride, b
         out[(size_t)pos * stride] = g;
         ++n;
     }
-    *hull = s.vuse[0] != 0;
+    *hull = s.v[0].use != 0;
     return n;
 }
 

@@ -22,7 +22,7 @@ if [ -n "$PMC" ]; then
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    rm -rf $R/gpurun_out/pmc_delaunay/p$i
+    rm -rf $R/gpurun_out/pmc_delaunay/p$i; mkdir -p $R/gpurun_out/pmc_delaunay
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_delaunay/p$i -o run -- python $R/scripts/gpu_delaunay.py ${DELAUNAY_ARGS:-2000000 5} > $R/gpurun_out/pmc_delaunay/p$i.log 2>&1
   done
   cd $R
