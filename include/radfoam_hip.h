@@ -278,12 +278,17 @@ int rf_kd_order(const float *points, uint32_t num_points, uint32_t *permutation,
  *       [1] stars that failed (degenerate or cospherical neighbourhood), [2] stars that needed the large instance,
  *       [3] points that coincide with another point, [4] directed edges whose reverse is missing,
  *       [5..6] tree nodes visited (low, high word), [7] link insertions, [8..10] the failed stars of [1] by cause
- *       (no non-coplanar start, link no longer a sphere, more than 249 neighbours), [11] hull candidates.
+ *       (no non-coplanar start, link no longer a sphere, beyond the limits below), [11] hull candidates.
  *       [1], [3] or [4] non-zero = what the
  *       reference reports by throwing TriangulationFailedError ("ambiguous triangulation", "duplicate points
  *       found"): the caller perturbs the points and retries (radfoam_model/scene.py:160-186).
- *   workspace: rf_delaunay_workspace_bytes(num_points) device bytes. */
+ *   workspace: rf_delaunay_workspace_bytes(num_points) device bytes.  That holds result rows for one star in 32 in
+ *       the second pass (the stars on the rim of the cloud, a few per thousand).  If a cloud needs more, the call
+ *       returns RF_ERR_WORKSPACE with info[2] = how many; rf_delaunay_workspace_bytes_for(num_points, info[2]) is
+ *       the size to come back with.
+ *   Limits: 4095 neighbours per point, and at most 64 points with more than 249 (hubs inside empty shells). */
 size_t rf_delaunay_workspace_bytes(uint32_t num_points);
+size_t rf_delaunay_workspace_bytes_for(uint32_t num_points, uint32_t second_pass_stars);
 int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float *aabb_tree,
                           const uint32_t *seed_adjacency, const uint32_t *seed_offsets,
                           uint32_t *point_adjacency, uint32_t adjacency_capacity,

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RADFOAM_HIP_LIB") or os.path.join(_HERE, "libradfoam_hip.so")
 
 RF_OK = 0
+RF_ERR_WORKSPACE = -2
 RF_ATTR_FLOAT32 = 0
 RF_ATTR_FLOAT16 = 1
 
@@ -88,6 +89,7 @@ SYMBOLS = {
     "rf_kd_order_workspace_bytes": (C.c_size_t, [_U32]),
     "rf_kd_order": (_INT, [_P, _U32, _P, _P, _P, C.c_size_t, _P]),
     "rf_delaunay_workspace_bytes": (C.c_size_t, [_U32]),
+    "rf_delaunay_workspace_bytes_for": (C.c_size_t, [_U32, _U32]),
     "rf_delaunay_adjacency": (_INT, [_P, _U32, _P, _P, _P, _P, _U32, _P, _P, _P, C.c_size_t, _P]),
     "rf_adjacency_size": (_INT, [_U32, _P, C.POINTER(_U32), _P]),
     "rf_cast_accumulator": (_INT, [_P, C.c_size_t, _INT, _P, _P]),

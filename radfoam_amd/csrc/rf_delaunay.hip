@@ -16,6 +16,8 @@
 //   delaunay_star_coop_kernel second pass, one WAVE per star: the parked stars (rim of the cloud: half-spaces behind
 //                            hull facets and the huge balls of flat tetrahedra, 10^5 tree nodes a query) and stars
 //                            with more than 63 neighbours (room for 249); a few per thousand points
+//   delaunay_star_huge_kernel third pass: hubs with more than 249 neighbours (room for 4095), a block per star, shared
+//                            insertions; usually nothing to do
 //   csr_*                    degrees -> offsets (rocPRIM scan) -> adjacency, ascending per point like find_adjacency's
 //   symmetry_kernel          j in N(i) <=> i in N(j): exact predicates make independent stars agree; cospherical
 //                            input can break that, which is reported (the reference throws "ambiguous triangulation")
@@ -43,8 +45,14 @@ constexpr int kBigV = 250, kBigT = 496;
 constexpr int kBlockSeeds = 12;
 constexpr uint32_t kBigFlag = 0x80000000u;   // first word of the row of a second-pass star: flag | row in big_rows
 
+constexpr int kHugeV = 4096, kHugeT = 8188, kHugeHole = 1024;   // third instance: hubs
+constexpr int kHugeStars = 64;                                   // ... of which a build may have this many
+constexpr int kHugeWaves = 4;
+constexpr uint32_t kHugeFlag = 0x40000000u;   // first word of the row of a third-pass star: flag | row in huge_rows
+
 using SmallStar = star::Star<kSmallV, kSmallT>;
 using BigStar = star::Star<kBigV, kBigT>;
+using HugeStar = star::Star<kHugeV, kHugeT, uint16_t, kHugeHole>;
 
 static inline uint32_t tree_depth_of(uint32_t n) {
     uint32_t d = 0;
@@ -88,6 +96,7 @@ __global__ __launch_bounds__(256) void aabb_level_kernel(const float *__restrict
 struct StarCounters {
     uint32_t overflow;     // stars handed to the second pass (too large for the small instance, or parked)
     uint32_t hull;         // entries of the hull candidate list
+    uint32_t huge;         // stars the second pass handed on to the third (more than 249 neighbours)
     uint32_t failed[6];    // stars by star::Status (index 0 unused)
     uint32_t asymmetric;   // directed edges without their reverse
     uint32_t adjacency;    // E
@@ -205,7 +214,8 @@ struct CoopResult {
     bool duplicate;
 };
 
-__device__ CoopResult coop_search(const BigStar &s, const star::Tree &tr, const float *__restrict__ pts, int t,
+template <typename S>
+__device__ CoopResult coop_search(const S &s, const star::Tree &tr, const float *__restrict__ pts, int t,
                                   const uint32_t *__restrict__ hull_ids, uint32_t hull_count, uint32_t &visited) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint8_t f = s.t[t].f;
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
     const uint32_t *__restrict__ seed_adj, const uint32_t *__restrict__ seed_off,
     const uint32_t *__restrict__ overflow_list, const uint32_t *__restrict__ hull_list, uint32_t hull_count,
     uint32_t count, const uint32_t *__restrict__ rows, uint32_t *__restrict__ big_rows,
-    uint32_t *__restrict__ degree, StarCounters *__restrict__ counters) {
+    uint32_t *__restrict__ degree, uint32_t *__restrict__ huge_list, StarCounters *__restrict__ counters) {
     __shared__ BigStar s;
     __shared__ uint32_t seeds[kBigV];
     __shared__ int pick[kCoopWaves];
@@ -378,6 +388,18 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
     }
     if (tid != 0) return;
     atomicAdd(&counters->inserted, inserted);
+    if (s.status == star::kOverflow) {
+        // a hub: the third pass takes it, with what this pass found as its first candidates
+        const uint32_t slot = atomicAdd(&counters->huge, 1u);
+        if (slot < (uint32_t)kHugeStars) {
+            huge_list[slot] = w;
+            uint32_t c = 0;
+            for (int k = 1; k < kBigV; ++k)
+                if (s.v[k].use) big_rows[(size_t)w * kBigV + c++] = s.v[k].g;
+            degree[i] = c;
+            return;
+        }
+    }
     if (s.status != star::kOk) {
         atomicAdd(&counters->failed[s.status], 1u);
         degree[i] = 0;
@@ -387,6 +409,121 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
     degree[i] = (uint32_t)star::star_neighbours(s, big_rows + (size_t)w * kBigV, 1, &hull);
 }
 
+// ---- third pass: hubs ------------------------------------------------------------------------------------------------
+// A point inside an empty shell of thousands of points (a floater inside a densely sampled surface) has thousands of
+// Delaunay neighbours.  Such a star (room for 4095; state in global memory, 280 KB) gets a block of four waves: the
+// waves answer its open queries like the second pass does, and every insertion is shared -- all threads test the
+// link's triangles against the new point and list the hole, thread 0 re-triangulates it from that list.
+
+template <typename S>
+__device__ int block_insert(S &s, uint32_t gq, const float *q, uint32_t *hole, int *nhole) {
+    if (threadIdx.x == 0) *nhole = 0;
+    __syncthreads();
+    for (int t = (int)threadIdx.x; t < s.nt; t += (int)blockDim.x)
+        if (star::conflict(s, t, q)) {
+            s.t[t].f |= star::kMarked;
+            const int k = atomicAdd(nhole, 1);
+            if (k < S::kHole) hole[k] = (uint32_t)t;
+        }
+    __syncthreads();
+    int r = 0;
+    if (threadIdx.x == 0 && *nhole > 0) r = star::star_apply(s, gq, q, *nhole, *nhole <= S::kHole ? hole : nullptr);
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(64 * kHugeWaves) void delaunay_star_huge_kernel(
+    const float *__restrict__ pts, uint32_t n, const float *__restrict__ tree, uint32_t depth,
+    const uint32_t *__restrict__ overflow_list, const uint32_t *__restrict__ hull_list, uint32_t hull_count,
+    const uint32_t *__restrict__ huge_list, const uint32_t *__restrict__ big_rows, HugeStar *__restrict__ arena,
+    uint32_t *__restrict__ huge_rows, uint32_t *__restrict__ rows, uint32_t *__restrict__ degree,
+    StarCounters *__restrict__ counters) {
+    __shared__ uint32_t hole[kHugeHole];
+    __shared__ int nhole;
+    __shared__ int pick[kHugeWaves];
+    __shared__ CoopResult found[kHugeWaves];
+    __shared__ int ok;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const uint32_t total = counters->huge;
+    if (b == 0 && tid == 0 && total > (uint32_t)kHugeStars) atomicAdd(&counters->failed[star::kOverflow], total - kHugeStars);
+    if (b >= total || b >= (uint32_t)kHugeStars) return;
+    const uint32_t w = huge_list[b], i = overflow_list[w];
+    HugeStar &s = arena[b];
+    const star::Tree tr{tree, n, depth};
+    const uint32_t *seeds = big_rows + (size_t)w * kBigV;
+    const int ns = (int)degree[i];
+    uint32_t visited = 0, inserted = 0;
+    int used[3] = {-1, -1, -1};
+    if (tid == 0) {
+        star::star_reset(s, i, pts + 3 * (size_t)i);
+        star::star_first_tet(s, pts, seeds, ns, used);
+        pick[0] = used[0];
+        pick[1] = used[1];
+        pick[2] = used[2];
+        ok = s.status == star::kOk;
+    }
+    __syncthreads();
+    used[0] = pick[0];
+    used[1] = pick[1];
+    used[2] = pick[2];
+    for (int k = 0; k < ns && ok; ++k) {
+        if (k == used[0] || k == used[1] || k == used[2]) continue;
+        const float *q = pts + 3 * (size_t)seeds[k];
+        const int r = block_insert(s, seeds[k], q, hole, &nhole);
+        if (tid == 0) {
+            inserted += r > 0;
+            if (r < 0) ok = 0;
+        }
+        __syncthreads();
+    }
+    for (;;) {
+        if (tid == 0) {
+            int k = 0;
+            for (int v = 0; v < kHugeWaves; ++v) {
+                pick[v] = -1;
+                if (!ok || s.status != star::kOk) continue;
+                while (k < s.nt && (s.t[k].f & star::kCertified)) ++k;
+                if (k < s.nt) pick[v] = k++;
+            }
+        }
+        __syncthreads();
+        if (pick[0] < 0) break;
+        const int t = pick[wave];
+        if (t >= 0) {
+            const CoopResult r = coop_search(s, tr, pts, t, hull_list, hull_count, visited);
+            if ((tid & 63u) == 0) found[wave] = r;
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int v = 0; v < kHugeWaves; ++v) {
+                if (pick[v] < 0) continue;
+                if (found[v].duplicate) s.status = star::kDuplicate;
+                else if (found[v].id == star::kInfinity) s.t[pick[v]].f |= star::kCertified;
+            }
+        __syncthreads();
+        for (int v = 0; v < kHugeWaves; ++v) {
+            if (pick[v] < 0 || found[v].id == star::kInfinity || s.status != star::kOk) continue;   // block-uniform
+            const int r = block_insert(s, found[v].id, found[v].q, hole, &nhole);
+            if (tid == 0) inserted += r > 0;
+        }
+        __syncthreads();
+    }
+    if ((tid & 63u) == 0) {
+        const uint32_t old = atomicAdd(&counters->nodes_lo, visited);
+        if (old + visited < old) atomicAdd(&counters->nodes_hi, 1u);
+    }
+    if (tid != 0) return;
+    atomicAdd(&counters->inserted, inserted);
+    if (s.status != star::kOk) {
+        atomicAdd(&counters->failed[s.status], 1u);
+        degree[i] = 0;
+        return;
+    }
+    bool hull;
+    degree[i] = (uint32_t)star::star_neighbours(s, huge_rows + (size_t)b * kHugeV, 1, &hull);
+    rows[(size_t)i * kSmallV] = b | kHugeFlag;
+}
+
 // rows of the large instance are addressed through rows[i * kSmallV] = position in the overflow list
 __global__ __launch_bounds__(256) void mark_big_rows_kernel(const uint32_t *__restrict__ overflow_list, uint32_t count,
                                                             uint32_t *__restrict__ rows) {
@@ -394,15 +531,18 @@ __global__ __launch_bounds__(256) void mark_big_rows_kernel(const uint32_t *__re
     if (w < count) rows[(size_t)overflow_list[w] * kSmallV] = w | kBigFlag;
 }
 
-__device__ __forceinline__ const uint32_t *row_of(const uint32_t *rows, const uint32_t *big_rows, uint32_t i,
-                                                  uint32_t deg) {
-    const uint32_t *row = rows + (size_t)i * kSmallV;
-    if (deg && (row[0] & kBigFlag)) return big_rows + (size_t)(row[0] & ~kBigFlag) * kBigV;
+struct RowTables {
+    const uint32_t *rows, *big_rows, *huge_rows;
+};
+
+__device__ __forceinline__ const uint32_t *row_of(const RowTables &T, uint32_t i, uint32_t deg) {
+    const uint32_t *row = T.rows + (size_t)i * kSmallV;
+    if (deg && (row[0] & kBigFlag)) return T.big_rows + (size_t)(row[0] & ~kBigFlag) * kBigV;
+    if (deg && (row[0] & kHugeFlag)) return T.huge_rows + (size_t)(row[0] & ~kHugeFlag) * kHugeV;
     return row;
 }
 
-__global__ __launch_bounds__(256) void csr_gather_kernel(const uint32_t *__restrict__ rows,
-                                                         const uint32_t *__restrict__ big_rows,
+__global__ __launch_bounds__(256) void csr_gather_kernel(RowTables tables,
                                                          const uint32_t *__restrict__ degree,
                                                          const uint32_t *__restrict__ offsets, uint32_t n,
                                                          uint32_t capacity, uint32_t *__restrict__ adjacency,
@@ -412,23 +552,22 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(const uint32_t *__restr
     const uint32_t deg = degree[i], off = offsets[i];
     if (i == n - 1) counters->adjacency = off + deg;
     if (off + deg > capacity) return;
-    const uint32_t *row = row_of(rows, big_rows, i, deg);
+    const uint32_t *row = row_of(tables, i, deg);
     for (uint32_t k = 0; k < deg; ++k) adjacency[off + k] = row[k];
 }
 
-__global__ __launch_bounds__(256) void symmetry_kernel(const uint32_t *__restrict__ rows,
-                                                       const uint32_t *__restrict__ big_rows,
+__global__ __launch_bounds__(256) void symmetry_kernel(RowTables tables,
                                                        const uint32_t *__restrict__ degree, uint32_t n,
                                                        StarCounters *__restrict__ counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t deg = degree[i];
-    const uint32_t *row = row_of(rows, big_rows, i, deg);
+    const uint32_t *row = row_of(tables, i, deg);
     uint32_t missing = 0;
     for (uint32_t k = 0; k < deg; ++k) {
         const uint32_t j = row[k];
         const uint32_t dj = degree[j];
-        const uint32_t *rj = row_of(rows, big_rows, j, dj);
+        const uint32_t *rj = row_of(tables, j, dj);
         uint32_t lo = 0, hi = dj;
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -505,18 +644,23 @@ static KdLayout kd_layout(uint32_t n) {
 }
 
 struct DelaunayLayout {
-    size_t rows, degree, overflow, hull, counters, big_rows, scan_temp, scan_bytes, total;
-    uint32_t arena_stars;
+    size_t rows, degree, overflow, hull, counters, big_rows, huge_list, huge_rows, huge_arena, scan_temp, scan_bytes, total;
+    uint32_t second_rows;   // stars the second pass has result rows for
 };
 
-static DelaunayLayout delaunay_layout(uint32_t n) {
-    DelaunayLayout L{};
+static size_t scan_temp_bytes(uint32_t n) {
     size_t scan_bytes = 0;
     (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)n,
                                   rocprim::plus<uint32_t>(), (hipStream_t)0);
+    return scan_bytes;
+}
+
+static uint32_t default_second_rows(uint32_t n) { return n / 32 < 1024 ? 1024 : n / 32; }
+
+static DelaunayLayout delaunay_layout(uint32_t n, uint32_t second_rows, size_t scan_bytes) {
+    DelaunayLayout L{};
     L.scan_bytes = scan_bytes;
-    // result rows of the second pass: room for one star in 32
-    L.arena_stars = n / 32 < 1024 ? 1024 : n / 32;
+    L.second_rows = second_rows;
     size_t at = 0;
     auto take = [&](size_t bytes) {
         const size_t here = at;
@@ -528,7 +672,10 @@ static DelaunayLayout delaunay_layout(uint32_t n) {
     L.overflow = take((size_t)n * 4);
     L.hull = take((size_t)n * 4);
     L.counters = take(sizeof(StarCounters));
-    L.big_rows = take((size_t)L.arena_stars * kBigV * 4);
+    L.big_rows = take((size_t)second_rows * kBigV * 4);
+    L.huge_list = take((size_t)kHugeStars * 4);
+    L.huge_rows = take((size_t)kHugeStars * kHugeV * 4);
+    L.huge_arena = take((size_t)kHugeStars * sizeof(HugeStar));
     L.scan_temp = take(scan_bytes);
     L.total = at;
     return L;
@@ -597,7 +744,14 @@ int rf_kd_order(const float *points, uint32_t num_points, uint32_t *permutation,
     return check_launch("rf_kd_order");
 }
 
-size_t rf_delaunay_workspace_bytes(uint32_t num_points) { return delaunay_layout(num_points).total; }
+size_t rf_delaunay_workspace_bytes(uint32_t num_points) {
+    return delaunay_layout(num_points, default_second_rows(num_points), scan_temp_bytes(num_points)).total;
+}
+
+size_t rf_delaunay_workspace_bytes_for(uint32_t num_points, uint32_t second_pass_stars) {
+    const uint32_t rows = second_pass_stars > num_points ? num_points : second_pass_stars;
+    return delaunay_layout(num_points, rows < 1024 ? 1024 : rows, scan_temp_bytes(num_points)).total;
+}
 
 int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float *aabb_tree,
                           const uint32_t *seed_adjacency, const uint32_t *seed_offsets, uint32_t *point_adjacency,
@@ -610,9 +764,18 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_delaunay_adjacency: seed_adjacency and seed_offsets go together");
     if (num_points < 32)
         return fail(RF_ERR_INVALID_ARGUMENT, "Delaunay triangulation does not support less than 32 points");
-    const DelaunayLayout L = delaunay_layout(num_points);
-    if (!workspace || workspace_bytes < L.total)
+    // the workspace decides how many stars the second pass has rows for: the default size, or whatever larger one
+    // the caller came back with (rf_delaunay_workspace_bytes_for) after being told how many were needed
+    const size_t scan_bytes = scan_temp_bytes(num_points);
+    uint32_t second_rows = default_second_rows(num_points);
+    if (!workspace || workspace_bytes < delaunay_layout(num_points, second_rows, scan_bytes).total)
         return fail(RF_ERR_WORKSPACE, "workspace missing or smaller than rf_delaunay_workspace_bytes()");
+    while (second_rows < num_points) {
+        const uint32_t next = second_rows * 2 < num_points ? second_rows * 2 : num_points;
+        if (delaunay_layout(num_points, next, scan_bytes).total > workspace_bytes) break;
+        second_rows = next;
+    }
+    const DelaunayLayout L = delaunay_layout(num_points, second_rows, scan_bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
     char *base = static_cast<char *>(workspace);
     uint32_t *rows = reinterpret_cast<uint32_t *>(base + L.rows);
@@ -621,6 +784,10 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
     uint32_t *hull = reinterpret_cast<uint32_t *>(base + L.hull);
     StarCounters *counters = reinterpret_cast<StarCounters *>(base + L.counters);
     uint32_t *big_rows = reinterpret_cast<uint32_t *>(base + L.big_rows);
+    uint32_t *huge_list = reinterpret_cast<uint32_t *>(base + L.huge_list);
+    uint32_t *huge_rows = reinterpret_cast<uint32_t *>(base + L.huge_rows);
+    HugeStar *huge_arena = reinterpret_cast<HugeStar *>(base + L.huge_arena);
+    const RowTables tables{rows, big_rows, huge_rows};
     const uint32_t depth = tree_depth_of(num_points);
     const uint32_t blocks = (num_points + 63u) / 64u;
 
@@ -632,7 +799,7 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
         const long v = e ? atol(e) : 512;
         return v <= 0 ? 0xFFFFFFFFu : (uint32_t)v;
     }();
-    // RF_DELAUNAY_WAVES (4, 6 or 8 waves per SIMD; tuning only)
+    // RF_DELAUNAY_WAVES (4 or 6 waves per SIMD; tuning only)
     static const int waves = [] {
         const char *e = getenv("RF_DELAUNAY_WAVES");
         return e ? atoi(e) : 6;
@@ -641,18 +808,18 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
     hipLaunchKernelGGL(delaunay_star_kernel<W>, dim3(blocks), dim3(64), 0, s, points, num_points, aabb_tree, depth, \
                        seed_adjacency, seed_offsets, rows, degree, overflow, hull, ghost_budget, counters)
     if (waves <= 4) RF_LAUNCH_STARS(4);
-    else if (waves >= 8) RF_LAUNCH_STARS(8);
     else RF_LAUNCH_STARS(6);
 #undef RF_LAUNCH_STARS
     StarCounters host{};
     if (hipMemcpyAsync(&host, counters, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
         return check_launch("rf_delaunay_adjacency: star kernel");
-    if (host.overflow > L.arena_stars) {
-        // more second-pass stars than there are rows for: not a point cloud this is sized for
-        info[0] = 0; info[1] = host.overflow; info[2] = host.overflow;
-        for (int k = 3; k < 12; ++k) info[k] = 0;
-        return fail(RF_ERR_WORKSPACE, "rf_delaunay_adjacency: more stars need the second pass than it has rows for");
+    if (host.overflow > L.second_rows) {
+        // more second-pass stars than this workspace has rows for: info[2] says how many, the caller comes back
+        // with rf_delaunay_workspace_bytes_for(num_points, info[2])
+        for (int k = 0; k < 12; ++k) info[k] = 0;
+        info[2] = host.overflow;
+        return fail(RF_ERR_WORKSPACE, "rf_delaunay_adjacency: more stars need the second pass than the workspace has rows for");
     }
     if (host.overflow) {
         // ghost queries of the second pass scan the hull candidates; a cloud with most of its points on its hull (a
@@ -666,13 +833,17 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
     hipLaunchKernelGGL(delaunay_star_coop_kernel<W>, dim3(host.overflow), dim3(64 * W), 0, s, points, num_points,    \
                        aabb_tree, depth, seed_adjacency, seed_offsets, overflow,                                     \
                        use_list ? hull : (const uint32_t *)nullptr, host.hull, host.overflow, rows, big_rows, degree, \
-                       counters)
+                       huge_list, counters)
         if (coop_waves >= 4) RF_LAUNCH_COOP(4);
         else if (coop_waves >= 2) RF_LAUNCH_COOP(2);
         else RF_LAUNCH_COOP(1);
 #undef RF_LAUNCH_COOP
         hipLaunchKernelGGL(mark_big_rows_kernel, dim3((host.overflow + 255u) / 256u), dim3(256), 0, s, overflow,
                            host.overflow, rows);
+        // third pass: whatever the second handed on (usually nothing: the blocks look at the counter and leave)
+        hipLaunchKernelGGL(delaunay_star_huge_kernel, dim3(kHugeStars), dim3(64 * kHugeWaves), 0, s, points, num_points,
+                           aabb_tree, depth, overflow, use_list ? hull : (const uint32_t *)nullptr, host.hull, huge_list,
+                           big_rows, huge_arena, huge_rows, rows, degree, counters);
     }
     size_t bytes = L.scan_bytes;
     if (rocprim::exclusive_scan(base + L.scan_temp, bytes, degree, point_adjacency_offsets, 0u, (size_t)num_points,
@@ -680,9 +851,9 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
         return fail(RF_ERR_LAUNCH, "rf_delaunay_adjacency: scan failed");
     hipLaunchKernelGGL(last_offset_kernel, dim3(1), dim3(1), 0, s, degree, point_adjacency_offsets, num_points);
     const uint32_t pb = (num_points + 255u) / 256u;
-    hipLaunchKernelGGL(csr_gather_kernel, dim3(pb), dim3(256), 0, s, rows, big_rows, degree, point_adjacency_offsets,
+    hipLaunchKernelGGL(csr_gather_kernel, dim3(pb), dim3(256), 0, s, tables, degree, point_adjacency_offsets,
                        num_points, adjacency_capacity, point_adjacency, counters);
-    hipLaunchKernelGGL(symmetry_kernel, dim3(pb), dim3(256), 0, s, rows, big_rows, degree, num_points, counters);
+    hipLaunchKernelGGL(symmetry_kernel, dim3(pb), dim3(256), 0, s, tables, degree, num_points, counters);
     if (hipMemcpyAsync(&host, counters, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
         return check_launch("rf_delaunay_adjacency: assembly");

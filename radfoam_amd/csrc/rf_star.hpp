@@ -324,45 +324,50 @@ struct Vert {
     uint32_t use;    // triangles using the slot; 0 = free
 };
 
-struct Tri {
-    uint8_t a, b, c, f;    // link triangle (a,b,c) with det[a-i; b-i; c-i] > 0; f = TriFlag bits
+template <typename Idx>
+struct TriT {
+    Idx a, b, c;           // link triangle (a,b,c) with det[a-i; b-i; c-i] > 0
+    uint8_t f;             // TriFlag bits
     float sx, sy, sz, sr;  // finite: circumcentre relative to p_i and squared radius; ghost: outward normal of the facet
 };
 
-template <int V, int T>
+// V link vertices, T link triangles (a closed link of v vertices has 2v - 4), Idx wide enough for a vertex slot;
+// HOLE = room of the list of hole triangles an insertion may be given (0: the insertion scans the flags instead)
+template <int V, int T, typename Idx = uint8_t, int HOLE = 0>
 struct Star {
-    static constexpr int kV = V, kT = T;
+    static constexpr int kV = V, kT = T, kHole = HOLE;
+    using Index = Idx;
     uint32_t self;
     int status;
     int nt;
     float p[3];
     Vert v[V];
-    Tri t[T];
+    TriT<Idx> t[T];
 };
 
-template <int V, int T>
-RF_STAR_FN void star_reset(Star<V, T> &s, uint32_t self, const float *p) {
+template <typename S>
+RF_STAR_FN void star_reset(S &s, uint32_t self, const float *p) {
     s.self = self;
     s.status = kOk;
     s.nt = 0;
     s.p[0] = p[0];
     s.p[1] = p[1];
     s.p[2] = p[2];
-    for (int k = 0; k < V; ++k) s.v[k].use = 0;
+    for (int k = 0; k < S::kV; ++k) s.v[k].use = 0;
     s.v[0].g = kInfinity;
     s.v[0].x = s.v[0].y = s.v[0].z = 0.0f;
 }
 
-template <int V, int T>
-RF_STAR_FN void vertex_xyz(const Star<V, T> &s, int slot, float *out) {
+template <typename S>
+RF_STAR_FN void vertex_xyz(const S &s, int slot, float *out) {
     out[0] = s.v[slot].x;
     out[1] = s.v[slot].y;
     out[2] = s.v[slot].z;
 }
 
 // the two finite vertices (u, v) of a ghost triangle, rotated so that infinity comes last
-template <int V, int T>
-RF_STAR_FN void ghost_edge(const Star<V, T> &s, int t, int &u, int &v) {
+template <typename S>
+RF_STAR_FN void ghost_edge(const S &s, int t, int &u, int &v) {
     const int a = s.t[t].a, b = s.t[t].b, c = s.t[t].c;
     if (c == 0) {
         u = a;
@@ -376,8 +381,8 @@ RF_STAR_FN void ghost_edge(const Star<V, T> &s, int t, int &u, int &v) {
     }
 }
 
-template <int V, int T>
-RF_STAR_FN void set_sphere(Star<V, T> &s, int t) {
+template <typename S>
+RF_STAR_FN void set_sphere(S &s, int t) {
     const int a = s.t[t].a, b = s.t[t].b, c = s.t[t].c;
     uint8_t flags = 0;
     if (a == 0 || b == 0 || c == 0) {
@@ -441,8 +446,8 @@ RF_STAR_FN void set_sphere(Star<V, T> &s, int t) {
 }
 
 // does the point q (global coordinates) conflict with triangle t?  Exact.
-template <int V, int T>
-RF_STAR_FN bool conflict(const Star<V, T> &s, int t, const float *q) {
+template <typename S>
+RF_STAR_FN bool conflict(const S &s, int t, const float *q) {
     const float qx = q[0] - s.p[0], qy = q[1] - s.p[1], qz = q[2] - s.p[2];
     const uint8_t f = s.t[t].f;
     if (f & kGhost) {
@@ -474,15 +479,15 @@ RF_STAR_FN bool conflict(const Star<V, T> &s, int t, const float *q) {
     return insphere_sign(s.p, pa, pb, pc, q) < 0;
 }
 
-template <int V, int T>
-RF_STAR_FN bool has_directed_edge(const Star<V, T> &s, int t, int u, int v) {
+template <typename S>
+RF_STAR_FN bool has_directed_edge(const S &s, int t, int u, int v) {
     const int a = s.t[t].a, b = s.t[t].b, c = s.t[t].c;
     return (a == u && b == v) || (b == u && c == v) || (c == u && a == v);
 }
 
 // first tetrahedron (i, a, b, c) + its three ghosts.  false: the four points are coplanar.
-template <int V, int T>
-RF_STAR_FN bool star_init(Star<V, T> &s, uint32_t ga, const float *pa, uint32_t gb, const float *pb, uint32_t gc,
+template <typename S>
+RF_STAR_FN bool star_init(S &s, uint32_t ga, const float *pa, uint32_t gb, const float *pb, uint32_t gc,
                           const float *pc) {
     const int o = orient_sign(s.p, pa, pb, pc);
     if (o == 0) return false;
@@ -494,11 +499,11 @@ RF_STAR_FN bool star_init(Star<V, T> &s, uint32_t ga, const float *pa, uint32_t 
     s.v[2].x = q2[0]; s.v[2].y = q2[1]; s.v[2].z = q2[2];
     s.v[3].x = pc[0]; s.v[3].y = pc[1]; s.v[3].z = pc[2];
     // (1,2,3), (2,1,inf), (3,2,inf), (1,3,inf): every directed edge once, its reverse once
-    const uint8_t tri[4][3] = {{1, 2, 3}, {2, 1, 0}, {3, 2, 0}, {1, 3, 0}};
+    const int tri[4][3] = {{1, 2, 3}, {2, 1, 0}, {3, 2, 0}, {1, 3, 0}};
     for (int t = 0; t < 4; ++t) {
-        s.t[t].a = tri[t][0];
-        s.t[t].b = tri[t][1];
-        s.t[t].c = tri[t][2];
+        s.t[t].a = (typename S::Index)tri[t][0];
+        s.t[t].b = (typename S::Index)tri[t][1];
+        s.t[t].c = (typename S::Index)tri[t][2];
     }
     s.nt = 4;
     s.v[0].use = 3;
@@ -507,19 +512,26 @@ RF_STAR_FN bool star_init(Star<V, T> &s, uint32_t ga, const float *pa, uint32_t 
     return true;
 }
 
-// Bowyer-Watson on the link.  Returns the number of triangles removed (0: q is not a neighbour), -1 on failure.
-template <int V, int T>
-RF_STAR_FN int star_insert(Star<V, T> &s, uint32_t gq, const float *q) {
-    const int nt0 = s.nt;
+// Bowyer-Watson on the link, in two steps so that a block of threads can share the first one.
+// star_mark: flag the triangles q conflicts with; returns how many.
+template <typename S>
+RF_STAR_FN int star_mark(S &s, const float *q) {
     int marked = 0;
-    for (int t = 0; t < nt0; ++t)
+    for (int t = 0; t < s.nt; ++t)
         if (conflict(s, t, q)) {
             s.t[t].f |= kMarked;
             ++marked;
         }
-    if (marked == 0) return 0;
+    return marked;
+}
+
+// star_apply: the flagged triangles (`marked` of them; `hole` = their indices if the caller collected them, else
+// null) come out and the hole is fanned to q.  Returns `marked`, or -1 on failure.
+template <typename S>
+RF_STAR_FN int star_apply(S &s, uint32_t gq, const float *q, int marked, const uint32_t *hole) {
+    const int nt0 = s.nt;
     int slot = -1;
-    for (int k = 1; k < V; ++k)
+    for (int k = 1; k < S::kV; ++k)
         if (s.v[k].use == 0) {
             slot = k;
             break;
@@ -534,22 +546,26 @@ RF_STAR_FN int star_insert(Star<V, T> &s, uint32_t gq, const float *q) {
     s.v[slot].z = q[2];
     // every directed edge of the hole whose reverse is not in the hole lies on its boundary: fan it to q
     int nt = nt0;
-    for (int t = 0; t < nt0; ++t) {
+    const int outer = hole ? marked : nt0;
+    for (int o = 0; o < outer; ++o) {
+        const int t = hole ? (int)hole[o] : o;
         if (!(s.t[t].f & kMarked)) continue;
         const int v3[4] = {s.t[t].a, s.t[t].b, s.t[t].c, s.t[t].a};
         for (int e = 0; e < 3; ++e) {
             const int u = v3[e], v = v3[e + 1];
             bool inner = false;
-            for (int t2 = 0; t2 < nt0 && !inner; ++t2)
+            for (int i2 = 0; i2 < outer && !inner; ++i2) {
+                const int t2 = hole ? (int)hole[i2] : i2;
                 inner = (s.t[t2].f & kMarked) && t2 != t && has_directed_edge(s, t2, v, u);
+            }
             if (inner) continue;
-            if (nt >= T) {
+            if (nt >= S::kT) {
                 s.status = kOverflow;
                 return -1;
             }
-            s.t[nt].a = (uint8_t)u;
-            s.t[nt].b = (uint8_t)v;
-            s.t[nt].c = (uint8_t)slot;
+            s.t[nt].a = (typename S::Index)u;
+            s.t[nt].b = (typename S::Index)v;
+            s.t[nt].c = (typename S::Index)slot;
             s.t[nt].f = 0;
             ++s.v[u].use;
             ++s.v[v].use;
@@ -580,6 +596,21 @@ RF_STAR_FN int star_insert(Star<V, T> &s, uint32_t gq, const float *q) {
     return marked;
 }
 
+// Returns the number of triangles removed (0: q is not a neighbour), -1 on failure.
+template <typename S>
+RF_STAR_FN int star_insert(S &s, uint32_t gq, const float *q) {
+    const int marked = star_mark(s, q);
+    if (marked == 0) return 0;
+    if (S::kHole > 0 && marked <= S::kHole) {   // large instances: the hole is a handful of thousands of triangles
+        uint32_t hole[S::kHole > 0 ? S::kHole : 1];
+        int n = 0;
+        for (int t = 0; t < s.nt && n < marked; ++t)
+            if (s.t[t].f & kMarked) hole[n++] = (uint32_t)t;
+        return star_apply(s, gq, q, marked, hole);
+    }
+    return star_apply(s, gq, q, marked, nullptr);
+}
+
 RF_STAR_FN float box_dist2(const float *nd, float x, float y, float z) {
     const float dx = fmaxf(fmaxf(nd[0] - x, x - nd[3]), 0.0f);
     const float dy = fmaxf(fmaxf(nd[1] - y, y - nd[4]), 0.0f);
@@ -590,8 +621,8 @@ RF_STAR_FN float box_dist2(const float *nd, float x, float y, float z) {
 // The point in strict conflict with triangle t that is closest to p_i, or kInfinity if there is none: depth-first
 // through the implicit tree, nearer child first, boxes pruned against the triangle's ball (half-space) and against
 // the best candidate so far.  `visited` counts tree nodes (instrumentation).
-template <int V, int T>
-RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts, int t, const HullSet &hull,
+template <typename S>
+RF_STAR_FN uint32_t star_search(S &s, const Tree &tr, const float *pts, int t, const HullSet &hull,
                                 float *out_q, uint32_t &visited) {
     const uint8_t f = s.t[t].f;
     const bool ghost = (f & kGhost) != 0;
@@ -713,29 +744,33 @@ RF_STAR_FN uint32_t star_search(Star<V, T> &s, const Tree &tr, const float *pts,
     return best_id;
 }
 
-// First tetrahedron + all the seeds (any order; nearest first is cheapest).
-template <int V, int T>
-RF_STAR_FN void star_seed(Star<V, T> &s, const float *pts, const uint32_t *seeds, int nseeds, uint32_t &inserted) {
-    // starting tetrahedron: the first seed triple that is not coplanar with p_i
-    int i0 = -1, i1 = -1, i2 = -1;
-    for (int a = 0; a < nseeds && i0 < 0; ++a)
-        for (int b = a + 1; b < nseeds && i0 < 0; ++b)
+// Starting tetrahedron: the first seed triple that is not coplanar with p_i.  Sets kDegenerate if there is none.
+template <typename S>
+RF_STAR_FN void star_first_tet(S &s, const float *pts, const uint32_t *seeds, int nseeds, int *used) {
+    used[0] = used[1] = used[2] = -1;
+    for (int a = 0; a < nseeds && used[0] < 0; ++a)
+        for (int b = a + 1; b < nseeds && used[0] < 0; ++b)
             for (int c = b + 1; c < nseeds; ++c) {
                 const float *pa = pts + 3 * (size_t)seeds[a], *pb = pts + 3 * (size_t)seeds[b];
                 const float *pc = pts + 3 * (size_t)seeds[c];
                 if (star_init(s, seeds[a], pa, seeds[b], pb, seeds[c], pc)) {
-                    i0 = a;
-                    i1 = b;
-                    i2 = c;
+                    used[0] = a;
+                    used[1] = b;
+                    used[2] = c;
                     break;
                 }
             }
-    if (i0 < 0) {
-        s.status = kDegenerate;
-        return;
-    }
+    if (used[0] < 0) s.status = kDegenerate;
+}
+
+// First tetrahedron + all the seeds (any order; nearest first is cheapest).
+template <typename S>
+RF_STAR_FN void star_seed(S &s, const float *pts, const uint32_t *seeds, int nseeds, uint32_t &inserted) {
+    int used[3];
+    star_first_tet(s, pts, seeds, nseeds, used);
+    if (s.status != kOk) return;
     for (int k = 0; k < nseeds; ++k) {
-        if (k == i0 || k == i1 || k == i2) continue;
+        if (k == used[0] || k == used[1] || k == used[2]) continue;
         const float *q = pts + 3 * (size_t)seeds[k];
         if (q[0] == s.p[0] && q[1] == s.p[1] && q[2] == s.p[2]) {
             s.status = kDuplicate;
@@ -747,8 +782,8 @@ RF_STAR_FN void star_seed(Star<V, T> &s, const float *pts, const uint32_t *seeds
 }
 
 // Build the star from `nseeds` candidate points, then certify every triangle.
-template <int V, int T>
-RF_STAR_FN void star_build(Star<V, T> &s, const Tree &tr, const float *pts, const HullSet &hull,
+template <typename S>
+RF_STAR_FN void star_build(S &s, const Tree &tr, const float *pts, const HullSet &hull,
                            const uint32_t *seeds, int nseeds, uint32_t &visited, uint32_t &inserted) {
     star_seed(s, pts, seeds, nseeds, inserted);
     if (s.status != kOk) return;
@@ -776,10 +811,10 @@ RF_STAR_FN void star_build(Star<V, T> &s, const Tree &tr, const float *pts, cons
 }
 
 // Neighbours in ascending order (finite link vertices); returns the count.  *hull = the star has a ghost.
-template <int V, int T>
-RF_STAR_FN int star_neighbours(const Star<V, T> &s, uint32_t *out, int stride, bool *hull) {
+template <typename S>
+RF_STAR_FN int star_neighbours(const S &s, uint32_t *out, int stride, bool *hull) {
     int n = 0;
-    for (int k = 1; k < V; ++k) {
+    for (int k = 1; k < S::kV; ++k) {
         if (s.v[k].use == 0) continue;
         const uint32_t g = s.v[k].g;
         int pos = n;

@@ -106,6 +106,12 @@ def delaunay_adjacency(points: torch.Tensor, tree: torch.Tensor | None = None, s
         with torch.cuda.device(dev):
             rc = lib.rf_delaunay_adjacency(_ptr(p), n, _ptr(tree), _ptr(seed_adj), _ptr(seed_off), _ptr(adj), capacity,
                                            _ptr(off), info, _ptr(ws), ws.numel(), _stream(dev))
+        if rc == _lib.RF_ERR_WORKSPACE and info[2] > 0:
+            # more rim stars than the default workspace has rows for (a cloud that is mostly surface): come back larger
+            need = int(lib.rf_delaunay_workspace_bytes_for(n, int(info[2])))
+            if need > ws.numel():
+                ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                continue
         _lib.check(rc)
         if info[0] <= capacity:
             break
@@ -120,7 +126,7 @@ def delaunay_adjacency(points: torch.Tensor, tree: torch.Tensor | None = None, s
     if stats["failed_stars"] or stats["asymmetric_edges"]:
         raise TriangulationFailedError(
             "ambiguous triangulation (%d stars failed: %d without a non-coplanar start, %d inconsistent, %d with more "
-            "than 249 neighbours; %d unmatched edges)" % (stats["failed_stars"], stats["degenerate_stars"],
+            "than 4095 neighbours; %d unmatched edges)" % (stats["failed_stars"], stats["degenerate_stars"],
                                                           stats["broken_stars"], stats["oversized_stars"],
                                                           stats["asymmetric_edges"]))
     e = stats["adjacency_size"]

@@ -19,13 +19,14 @@ static uint32_t *g_star_ns = nullptr;   // per-star build time (instrumentation)
 
 // what delaunay_star_kernel / delaunay_star_big_kernel do per lane: seeds = the `knn` nearest points of the lane's
 // 64-point kd-block, or the old neighbour list when one is given
-template <int V, int T>
+template <typename StarT>
 static int one_star(const float *pts, uint32_t n, const Tree &tr, const HullSet &hull, uint32_t i, uint32_t knn,
                     const uint32_t *old_adj, const uint32_t *old_off, uint32_t *row, uint32_t *degree, uint8_t *ghost,
                     uint32_t *visited, uint32_t *inserted) {
-    static thread_local Star<V, T> s;
+    static thread_local StarT s;
+    constexpr int V = StarT::kV;
     star_reset(s, i, pts + 3 * (size_t)i);
-    uint32_t seeds[256];
+    static thread_local uint32_t seeds[4096];
     int ns = 0;
     if (old_adj) {
         for (uint32_t e = old_off[i]; e < old_off[i + 1] && ns < V - 1; ++e) seeds[ns++] = old_adj[e];
@@ -80,7 +81,7 @@ int star_host_delaunay(const float *pts, uint32_t n, const float *tree, uint32_t
     for (uint32_t i = 0; i < n; ++i) {
         visited[i] = inserted[i] = 0;
         hull[i] = 0;
-        status[i] = one_star<64, 124>(pts, n, tr, first, i, knn, old_adj, old_off, rows + (size_t)i * stride, degree,
+        status[i] = one_star<Star<64, 124>>(pts, n, tr, first, i, knn, old_adj, old_off, rows + (size_t)i * stride, degree,
                                       hull, visited, inserted);
     }
     // hull candidates: stars that kept a ghost or were parked; second pass: the large instance for parked and
@@ -98,8 +99,13 @@ int star_host_delaunay(const float *pts, uint32_t n, const float *tree, uint32_t
 #pragma omp parallel for schedule(dynamic, 16) reduction(+ : bad)
     for (uint32_t i = 0; i < n; ++i) {
         if (status[i] == kPending || status[i] == kOverflow)
-            status[i] = one_star<250, 496>(pts, n, tr, second, i, knn, old_adj, old_off, rows + (size_t)i * stride,
+            status[i] = one_star<Star<250, 496>>(pts, n, tr, second, i, knn, old_adj, old_off, rows + (size_t)i * stride,
                                            degree, hull, visited, inserted);
+        // third tier (delaunay_star_huge_kernel): hubs with up to 4095 neighbours
+        if (status[i] == kOverflow && stride >= 4096)
+            status[i] = one_star<Star<4096, 8188, uint16_t, 1024>>(pts, n, tr, second, i, knn, old_adj, old_off,
+                                                                   rows + (size_t)i * stride, degree, hull, visited,
+                                                                   inserted);
         bad += status[i] != kOk;
     }
     return bad;

@@ -64,7 +64,7 @@ def aabb_tree(points: np.ndarray) -> np.ndarray:
     return tree
 
 
-def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250, ghost_budget: int = 2048):
+def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250, ghost_budget: int = 512):
     """(offsets, adjacency, info) through the host build of the star code."""
     pts = np.ascontiguousarray(points, dtype=np.float32)
     n = pts.shape[0]

@@ -89,6 +89,34 @@ def test_host_stars_equal_qhull(name):
     assert np.array_equal(off, off0) and np.array_equal(adj, adj0)
 
 
+def _hub_cloud(rng):
+    """A point at the centre of an empty shell of 3000 points (a floater inside a densely sampled surface): more
+    than 2000 Delaunay neighbours."""
+    shell = rng.normal(size=(3000, 3))
+    shell /= np.linalg.norm(shell, axis=1, keepdims=True)
+    outside = rng.uniform(-3, 3, size=(4000, 3))
+    outside = outside[np.linalg.norm(outside, axis=1) > 1.5]
+    return _kd(np.concatenate([shell * (1 + 1e-3 * rng.normal(size=(3000, 1))), np.zeros((1, 3)), outside]))
+
+
+def _shell_cloud(rng, n=20000):
+    """Every point on the rim: a fifth of the stars run out of budget in the first pass."""
+    shell = rng.normal(size=(n, 3))
+    shell /= np.linalg.norm(shell, axis=1, keepdims=True)
+    return _kd(shell * (1 + 1e-3 * rng.normal(size=(n, 1))))
+
+
+def test_host_hub_goes_through_the_third_instance():
+    pts = _hub_cloud(np.random.default_rng(0))
+    off0, adj0 = foam.delaunay_csr(pts)
+    assert np.diff(off0.astype(np.int64)).max() > 2000
+    _, _, info = S.delaunay(pts, stride=250)        # two instances only: the hub does not fit
+    assert info["bad"] == 1 and (info["status"] == 1).sum() == 1
+    off, adj, info = S.delaunay(pts, stride=4096)   # + Star<4096, 8188, uint16_t>: room for 4095 neighbours
+    assert info["bad"] == 0
+    assert np.array_equal(off, off0) and np.array_equal(adj, adj0)
+
+
 def test_host_incremental_seeds_give_the_same_lists():
     rng = np.random.default_rng(5)
     pts = _kd(rng.uniform(-1, 1, size=(8000, 3)))
@@ -174,6 +202,24 @@ def test_gpu_stars_equal_qhull(name):
     assert stats["asymmetric_edges"] == 0 and stats["failed_stars"] == 0
     if name == "sheet":
         assert stats["large_stars"] > 0   # the large instance was exercised
+
+
+@pytest.mark.gpu
+def test_gpu_hub_and_shell():
+    """The two clouds the default sizes are not made for: a hub with > 2000 neighbours (third pass, a block per star,
+    shared insertions) and a sphere shell whose rim stars outnumber the default second-pass rows (the call asks for a
+    larger workspace and the binding comes back with one)."""
+    from radfoam_amd import triangulation
+    pts = _hub_cloud(np.random.default_rng(0))
+    off0, adj0 = foam.delaunay_csr(pts)
+    adj, off, stats = triangulation.delaunay_adjacency(_t(pts))
+    assert int(np.diff(off.cpu().numpy().astype(np.int64)).max()) > 2000
+    assert np.array_equal(off.cpu().numpy(), off0) and np.array_equal(adj.cpu().numpy(), adj0)
+    pts = _shell_cloud(np.random.default_rng(2))
+    off0, adj0 = foam.delaunay_csr(pts)
+    adj, off, stats = triangulation.delaunay_adjacency(_t(pts))
+    assert stats["large_stars"] > 1024   # more than the default workspace has rows for
+    assert np.array_equal(off.cpu().numpy(), off0) and np.array_equal(adj.cpu().numpy(), adj0)
 
 
 @pytest.mark.gpu
