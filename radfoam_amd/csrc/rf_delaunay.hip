@@ -770,10 +770,10 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
     uint32_t second_rows = default_second_rows(num_points);
     if (!workspace || workspace_bytes < delaunay_layout(num_points, second_rows, scan_bytes).total)
         return fail(RF_ERR_WORKSPACE, "workspace missing or smaller than rf_delaunay_workspace_bytes()");
-    while (second_rows < num_points) {
-        const uint32_t next = second_rows * 2 < num_points ? second_rows * 2 : num_points;
-        if (delaunay_layout(num_points, next, scan_bytes).total > workspace_bytes) break;
-        second_rows = next;
+    for (uint32_t lo = second_rows, hi = num_points > second_rows ? num_points : second_rows; lo < hi;) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;   // the largest row count this workspace holds
+        if (delaunay_layout(num_points, mid, scan_bytes).total <= workspace_bytes) second_rows = lo = mid;
+        else hi = mid - 1;
     }
     const DelaunayLayout L = delaunay_layout(num_points, second_rows, scan_bytes);
     hipStream_t s = static_cast<hipStream_t>(stream);
