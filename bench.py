@@ -422,6 +422,37 @@ def main():
             detail["exchange_rows_per_rank"] = tracer.sparse.last_counts
             detail["exchange_bytes_in_per_rank"] = int((world - 1) * max(tracer.sparse.last_counts) * pitch * 4)
             detail["dense_allreduce_bytes_per_rank"] = int(2 * (world - 1) / world * points.shape[0] * (3 + A) * 4)
+    if on_gpu and world == 1 and args.workload == "north-star" and not W.get("custom"):
+        # what train.py:243-248 does between steps: the triangulation follows the points.  Untimed extra, beside the
+        # metric: the foam's own lists rebuilt on the GPU from scratch (and compared with the lists the frame was traced
+        # through: Qhull's, when they came from the cache), then an incremental rebuild after a 3 %-of-the-spacing move.
+        from radfoam_amd import triangulation
+
+        def timed_ms(fn):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize(dev)
+            return out, (time.perf_counter() - t0) * 1e3
+
+        triangulation.delaunay_adjacency(points)   # warm-up (module load, allocator)
+        tree, tree_ms = timed_ms(lambda: triangulation.build_aabb_tree(points))
+        (t_adj, t_off, t_stats), full_ms = timed_ms(lambda: triangulation.delaunay_adjacency(points, tree))
+        g = torch.Generator(device=dev).manual_seed(7)
+        moved = points + 0.03 * (8.0 / points.shape[0]) ** (1.0 / 3.0) * torch.randn(points.shape, device=dev, generator=g)
+        tree2 = triangulation.build_aabb_tree(moved)
+        (m_adj, m_off, _), inc_ms = timed_ms(lambda: triangulation.delaunay_adjacency(moved, tree2, (t_adj, t_off)))
+        detail["triangulation"] = {
+            "points": int(points.shape[0]), "aabb_tree_ms": round(tree_ms, 3), "from_scratch_ms": round(full_ms, 1),
+            "incremental_ms": round(inc_ms, 1),
+            "equals_traced_lists": bool(torch.equal(t_adj.view(torch.int32), adjacency.view(torch.int32)) and
+                                        torch.equal(t_off.view(torch.int32), offsets.view(torch.int32))),
+            "traced_lists_from": fm["csr_source"], "second_pass_stars": t_stats["large_stars"],
+            "tree_nodes_per_point": round(t_stats["tree_nodes_visited"] / points.shape[0], 1),
+            "lists_changed_by_the_move": bool(m_adj.numel() != t_adj.numel() or
+                                              not torch.equal(m_adj.view(torch.int32), t_adj.view(torch.int32))),
+        }
+        del tree, tree2, t_adj, t_off, m_adj, m_off, moved
     roofline = None
     if on_gpu and W["kind"] != "render" and rank == 0:
         my_rays = tracer._shard(rays) if strong else rays
