@@ -164,7 +164,7 @@ class Triangulation:
         tree = build_aabb_tree(sorted_pts)
         adj, off, self.stats = delaunay_adjacency(sorted_pts, tree, seed)
         self._n = pts.size(0)
-        self._points = sorted_pts
+        self._points = sorted_pts.clone() if sorted_pts is pts else sorted_pts   # not the caller's (mutable) storage
         self._adjacency, self._offsets = adj, off
         self._host = None
         # whatever the tracer packed from the old lists is stale, even if a caller hands the new ones out at the old
