@@ -39,6 +39,10 @@
 #error "define RF_STAR_FN, RF_STAR_NOINLINE and RF_STAR_NOUNROLL before including rf_star.hpp"
 #endif
 
+#ifndef RF_STAR_TRACE_QUERY   // instrumentation hook of the host harness: (tree nodes of the query, found a point)
+#define RF_STAR_TRACE_QUERY(nodes, found) ((void)0)
+#endif
+
 namespace rf {
 namespace star {
 
@@ -796,7 +800,9 @@ RF_STAR_FN void star_build(S &s, const Tree &tr, const float *pts, const HullSet
             }
         if (t < 0) break;
         float q[3];
+        const uint32_t before = visited;
         const uint32_t j = star_search(s, tr, pts, t, hull, q, visited);
+        RF_STAR_TRACE_QUERY(visited - before, j != kInfinity);
         if (s.status != kOk) return;
         if (j == kInfinity) {
             s.t[t].f |= kCertified;

@@ -1,0 +1,32 @@
+"""CPU-only model of the first pass of the GPU triangulation: per-query tree-node counts of 12,800
+stars from the host build of rf_star.hpp (tests/host_harness), and what a wave that runs 64 of them in lockstep --
+query k of every lane at the same time, as delaunay_star_kernel does -- pays for it.
+  python scripts/model_star_lockstep.py"""
+import sys, ctypes as C
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from tests.host_harness import star_host as S
+from radfoam_amd import foam
+n = 200000
+fm = foam.make_synthetic_foam(n, 0, 11, cache_dir=foam.default_cache_dir())
+pts = fm["points"]; tree = S.aabb_tree(pts); depth = S.pow2_round_up(n).bit_length() - 1
+L = S.lib(); L.star_host_trace.restype = C.c_int
+first, count, cap = 64 * 1000, 64 * 200, 160
+out = np.zeros((count, cap), dtype=np.uint32); lens = np.zeros(count, dtype=np.uint32)
+L.star_host_trace(C.c_void_p(pts.ctypes.data), C.c_uint32(n), C.c_void_p(tree.ctypes.data), C.c_uint32(depth), C.c_uint32(12), C.c_uint32(512),
+                  C.c_uint32(first), C.c_uint32(count), C.c_uint32(cap), C.c_void_p(out.ctypes.data), C.c_void_p(lens.ctypes.data))
+nodes = (out & 0x7FFFFFFF).astype(np.int64); found = (out >> 31).astype(bool)
+mask = np.arange(cap)[None, :] < lens[:, None]
+print("queries/star %.1f (found %.1f) nodes/query mean %.1f median %.0f p90 %.0f p99 %.0f max %d" % (lens.mean(), (found & mask).sum(1).mean(), nodes[mask].mean(), np.median(nodes[mask]), np.percentile(nodes[mask], 90), np.percentile(nodes[mask], 99), nodes[mask].max()))
+W = nodes.reshape(-1, 64, cap); M = mask.reshape(-1, 64, cap)
+per_lane_total = (W * M).sum(2)                      # nodes per star
+lockstep = (W * M).max(1).sum(1)                     # sum over query index of the max over lanes
+ideal = per_lane_total.max(1)
+print("per wave: mean lane total %.0f, max lane total %.0f, lockstep (query-synchronous) %.0f -> efficiency mean/lockstep %.2f, mean/maxlane %.2f" % (per_lane_total.mean(), ideal.mean(), lockstep.mean(), per_lane_total.mean() / lockstep.mean(), per_lane_total.mean() / ideal.mean()))
+# `width` lanes per star (a wave handles 64/width stars at a time, 64 stars take `width` rounds), a query of L nodes
+# taking about L / eff + 2 steps of the sub-wave
+for width, eff in ((8, 3.0), (16, 4.5)):
+    steps = np.ceil(nodes / eff) + 2
+    S_ = (steps * mask).reshape(-1, width, 64 // width, cap)    # [wave, round, concurrent star, query]
+    cost = S_.max(2).sum(2).sum(1)                              # per round lockstep over concurrent stars, rounds add
+    print("sub-wave width %d (assumed %.1f nodes per step): steps per 64 stars %.0f (now %.0f)" % (width, eff, cost.mean(), lockstep.mean()))

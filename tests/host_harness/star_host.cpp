@@ -8,6 +8,14 @@
 #include <vector>
 #include <chrono>
 
+// per-query trace (tree nodes, found-a-point) of the star being built, for the SIMT-cost model in star_host.py
+#include <utility>
+static thread_local std::vector<std::pair<uint32_t, int>> *g_trace = nullptr;
+#define RF_STAR_TRACE_QUERY(nodes, found) \
+    do {                                  \
+        if (g_trace) g_trace->emplace_back((uint32_t)(nodes), (int)(found)); \
+    } while (0)
+
 #define RF_STAR_FN static inline
 #define RF_STAR_NOINLINE static __attribute__((noinline))
 #define RF_STAR_NOUNROLL
@@ -112,5 +120,28 @@ int star_host_delaunay(const float *pts, uint32_t n, const float *tree, uint32_t
 }
 
 const uint32_t *star_host_times() { return g_star_ns; }
+
+// First-pass query traces of the stars [first, first + count): out[k * cap + q] = tree nodes of query q of star k
+// (bit 31: the query found a point), lengths[k] = number of queries.  For the lockstep cost model.
+int star_host_trace(const float *pts, uint32_t n, const float *tree, uint32_t depth, uint32_t knn, uint32_t budget,
+                    uint32_t first, uint32_t count, uint32_t cap, uint32_t *out, uint32_t *lengths) {
+    Tree tr{tree, n, depth};
+    const HullSet pass{nullptr, 0, budget};
+    std::vector<uint32_t> row(4096), deg(n), vis(n), ins(n);
+    std::vector<uint8_t> ghost(n);
+    std::vector<uint32_t> ns_store(n, 0);
+    g_star_ns = ns_store.data();
+    for (uint32_t k = 0; k < count && first + k < n; ++k) {
+        std::vector<std::pair<uint32_t, int>> tr_q;
+        g_trace = &tr_q;
+        one_star<Star<64, 124>>(pts, n, tr, pass, first + k, knn, nullptr, nullptr, row.data(), deg.data(), ghost.data(),
+                                vis.data(), ins.data());
+        g_trace = nullptr;
+        lengths[k] = (uint32_t)(tr_q.size() < cap ? tr_q.size() : cap);
+        for (uint32_t q = 0; q < lengths[k]; ++q) out[(size_t)k * cap + q] = tr_q[q].first | (tr_q[q].second ? 0x80000000u : 0u);
+    }
+    g_star_ns = nullptr;
+    return 0;
+}
 
 }  // extern "C"
