@@ -286,7 +286,9 @@ int rf_kd_order(const float *points, uint32_t num_points, uint32_t *permutation,
  *       the second pass (the stars on the rim of the cloud, a few per thousand).  If a cloud needs more, the call
  *       returns RF_ERR_WORKSPACE with info[2] = how many; rf_delaunay_workspace_bytes_for(num_points, info[2]) is
  *       the size to come back with.
- *   Limits: 4095 neighbours per point, and at most 64 points with more than 249 (hubs inside empty shells). */
+ *   Limits: 4095 neighbours per point, and at most 64 points with more than 249 (hubs inside empty shells).
+ *   Environment (tuning / experiments, read at the call): RF_DELAUNAY_OWNER=1|2 selects the experimental two-pass
+ *   build that certifies every tetrahedron once (it also enlarges the workspace by 760 B per point). */
 size_t rf_delaunay_workspace_bytes(uint32_t num_points);
 size_t rf_delaunay_workspace_bytes_for(uint32_t num_points, uint32_t second_pass_stars);
 int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float *aabb_tree,

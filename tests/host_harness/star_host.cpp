@@ -119,6 +119,96 @@ int star_host_delaunay(const float *pts, uint32_t n, const float *tree, uint32_t
     return bad;
 }
 
+// The experimental two-pass build (rf_star.hpp: star_certify_owned / star_close), as the owner kernels of
+// rf_delaunay.hip run it: pass 1 certifies owned triangles and saves records, pass 2 closes the rest from the owners'
+// records or the tree; stars parked in either pass go to the large instance with the hull candidates, as in the
+// default build.  tree_knn = 0: seeds from the kd-block; 24: the 24 nearest points by a tree walk.
+int star_host_delaunay_owner(const float *pts, uint32_t n, const float *tree, uint32_t depth, uint32_t knn,
+                             uint32_t tree_knn, uint32_t budget, uint32_t *rows, int stride, uint32_t *degree,
+                             uint8_t *hull, int *status, double *stats) {
+    if (stride < 250) return -1;
+    using Small = Star<64, 124>;
+    using Rec = StarRecord<64, 124>;
+    Tree tr{tree, n, depth};
+    const HullSet first{nullptr, 0, budget};
+    std::vector<Rec> rec(n);
+    std::vector<uint32_t> ns_store(n, 0);
+    g_star_ns = ns_store.data();
+    double nodes1 = 0, nodes2 = 0, nodes_knn = 0, ins = 0, closed = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : nodes1, nodes_knn, ins)
+    for (uint32_t i = 0; i < n; ++i) {
+        static thread_local Small s;
+        star_reset(s, i, pts + 3 * (size_t)i);
+        uint32_t seeds[64];
+        int ns = 0;
+        uint32_t vis = 0, in = 0;
+        if (tree_knn) {
+            ns = star_knn<24>(tr, pts, i, seeds, vis);
+            nodes_knn += vis;
+            vis = 0;
+        } else {
+            const uint32_t b0 = i & ~63u, b1 = b0 + 64 < n ? b0 + 64 : n;
+            float d2[64];
+            for (uint32_t k = b0; k < b1; ++k) {
+                const float dx = pts[3 * k] - pts[3 * i], dy = pts[3 * k + 1] - pts[3 * i + 1], dz = pts[3 * k + 2] - pts[3 * i + 2];
+                d2[k - b0] = k == i ? 3.4e38f : dx * dx + dy * dy + dz * dz;
+            }
+            for (uint32_t r = 0; r < knn; ++r) {
+                int best = -1;
+                for (uint32_t k = 0; k < b1 - b0; ++k)
+                    if (d2[k] < 3.4e38f && (best < 0 || d2[k] < d2[best])) best = (int)k;
+                if (best < 0) break;
+                seeds[ns++] = b0 + (uint32_t)best;
+                d2[best] = 3.4e38f;
+            }
+        }
+        star_certify_owned(s, tr, pts, first, seeds, ns, vis, in);
+        star_save(s, rec[i]);
+        nodes1 += vis;
+        ins += in;
+    }
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : nodes2, ins, closed)
+    for (uint32_t i = 0; i < n; ++i) {
+        hull[i] = 0;
+        status[i] = rec[i].status;
+        if (rec[i].status != kOk) continue;
+        static thread_local Small s;
+        star_load(s, rec[i], i, pts);
+        uint32_t vis = 0, in = 0, cl = 0;
+        star_close(s, tr, pts, first,
+                   [&](uint32_t owner, uint32_t g0, uint32_t g1, uint32_t g2) { return record_certifies(rec[owner], 64, g0, g1, g2); },
+                   vis, in, cl);
+        nodes2 += vis;
+        ins += in;
+        closed += cl;
+        status[i] = s.status;
+        if (s.status != kOk) continue;
+        bool h;
+        degree[i] = (uint32_t)star_neighbours(s, rows + (size_t)i * stride, 1, &h);
+        hull[i] = h;
+    }
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < n; ++i)
+        if (hull[i] || status[i] != kOk) ids.push_back(i);
+    const HullSet second{ids.data(), (uint32_t)ids.size(), 0xFFFFFFFFu};
+    std::vector<uint32_t> vis2(n, 0), ins2(n, 0);
+    int bad = 0;
+    long redone = 0;
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : bad, redone)
+    for (uint32_t i = 0; i < n; ++i) {
+        if (status[i] == kPending || status[i] == kOverflow) {
+            status[i] = one_star<Star<250, 496>>(pts, n, tr, second, i, knn, nullptr, nullptr, rows + (size_t)i * stride,
+                                                 degree, hull, vis2.data(), ins2.data());
+            redone++;
+        }
+        bad += status[i] != kOk;
+    }
+    g_star_ns = nullptr;
+    stats[0] = nodes1 / n; stats[1] = nodes2 / n; stats[2] = nodes_knn / n; stats[3] = ins / n; stats[4] = closed / n;
+    stats[5] = (double)redone;
+    return bad;
+}
+
 const uint32_t *star_host_times() { return g_star_ns; }
 
 // First-pass query traces of the stars [first, first + count): out[k * cap + q] = tree nodes of query q of star k

@@ -37,6 +37,10 @@ def lib():
         _lib.star_host_delaunay.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_uint32]
+        _lib.star_host_delaunay_owner.restype = C.c_int
+        _lib.star_host_delaunay_owner.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                  C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]
     return _lib
 
 
@@ -90,3 +94,25 @@ def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250, gho
     adjacency = rows[mask]
     return offsets.astype(np.uint32), adjacency, dict(bad=bad, status=status, visited=visited, inserted=inserted,
                                                        hull=hull, degree=degree)
+
+
+def delaunay_owner(points: np.ndarray, tree_knn: int = 0, knn: int = 12, budget: int = 512, stride: int = 250):
+    """(offsets, adjacency, info) through the experimental two-pass build (every tetrahedron certified once)."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    n = pts.shape[0]
+    tree = aabb_tree(pts)
+    depth = pow2_round_up(n).bit_length() - 1
+    rows = np.zeros((n, stride), dtype=np.uint32)
+    degree = np.zeros(n, dtype=np.uint32)
+    hull = np.zeros(n, dtype=np.uint8)
+    status = np.zeros(n, dtype=np.int32)
+    stats = np.zeros(6)
+    bad = lib().star_host_delaunay_owner(pts.ctypes.data, n, tree.ctypes.data, depth, knn, tree_knn, budget,
+                                         rows.ctypes.data, stride, degree.ctypes.data, hull.ctypes.data,
+                                         status.ctypes.data, stats.ctypes.data)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(degree, out=offsets[1:])
+    adjacency = rows[np.arange(stride)[None, :] < degree[:, None]]
+    return offsets.astype(np.uint32), adjacency, dict(
+        bad=bad, status=status, nodes_pass1=stats[0], nodes_pass2=stats[1], nodes_knn=stats[2], insertions=stats[3],
+        closed_by_owner=stats[4], redone=int(stats[5]))

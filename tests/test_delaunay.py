@@ -117,6 +117,24 @@ def test_host_hub_goes_through_the_third_instance():
     assert np.array_equal(off, off0) and np.array_equal(adj, adj0)
 
 
+@pytest.mark.parametrize("tree_knn", [0, 24])
+def test_host_owner_build_equals_qhull(tree_knn):
+    """The experimental two-pass build (every tetrahedron certified once: rf_star.hpp star_certify_owned / star_close,
+    star records, the tree k-NN seeding) through the host harness: same lists, a third of the tree work."""
+    rng = np.random.default_rng(8)
+    for pts in (_kd(rng.uniform(-1, 1, size=(15000, 3))), _kd(_clustered(rng, 2000)),
+                _kd(np.concatenate([np.c_[rng.uniform(-1, 1, size=(4000, 2)), 1e-3 * rng.normal(size=4000)],
+                                    rng.uniform(-1, 1, size=(1000, 3))]))):
+        off0, adj0 = foam.delaunay_csr(pts)
+        _, _, base = S.delaunay(pts)
+        off, adj, info = S.delaunay_owner(pts, tree_knn=tree_knn)
+        assert info["bad"] == 0
+        assert np.array_equal(off, off0) and np.array_equal(adj, adj0)
+        assert info["closed_by_owner"] > 5   # certificates were really shared
+        total = info["nodes_pass1"] + info["nodes_pass2"] + info["nodes_knn"]
+        assert total < 0.85 * base["visited"].mean()
+
+
 def test_host_incremental_seeds_give_the_same_lists():
     rng = np.random.default_rng(5)
     pts = _kd(rng.uniform(-1, 1, size=(8000, 3)))
@@ -219,6 +237,21 @@ def test_gpu_hub_and_shell():
     off0, adj0 = foam.delaunay_csr(pts)
     adj, off, stats = triangulation.delaunay_adjacency(_t(pts))
     assert stats["large_stars"] > 1024   # more than the default workspace has rows for
+    assert np.array_equal(off.cpu().numpy(), off0) and np.array_equal(adj.cpu().numpy(), adj0)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(__import__("os").environ.get("RF_TEST_EXPERIMENTAL") != "1",
+                    reason="the two-pass owner build is host-validated only so far (DESIGN.md 7.4): "
+                           "RF_TEST_EXPERIMENTAL=1 runs it on the GPU")
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_gpu_owner_build_equals_qhull(mode, monkeypatch):
+    from radfoam_amd import triangulation
+    monkeypatch.setenv("RF_DELAUNAY_OWNER", mode)
+    rng = np.random.default_rng(13)
+    pts = _kd(rng.uniform(-1, 1, size=(60000, 3)))
+    off0, adj0 = foam.delaunay_csr(pts)
+    adj, off, stats = triangulation.delaunay_adjacency(_t(pts))
     assert np.array_equal(off.cpu().numpy(), off0) and np.array_equal(adj.cpu().numpy(), adj0)
 
 
