@@ -173,6 +173,8 @@ class HIPTracingPipeline : public Pipeline {
 
 void set_hip_pipeline_memory(const DeviceMemoryHooks &hooks) { g_mem = hooks; }
 
+DeviceMemoryHooks triangulation_memory() { return g_mem; }   // hip_triangulation.cpp allocates through the same hooks
+
 // prefetch_adjacent_diff, pipeline.h:46-53 (reference definition pipeline.cu:570-586)
 void prefetch_adjacent_diff(const Vec3f *points, uint32_t num_points, uint32_t point_adjacency_size,
                             const uint32_t *point_adjacency, const uint32_t *point_adjacency_offsets,

@@ -150,3 +150,76 @@ def test_reference_interface_matches_the_ctypes_path(foam_factory, d, half):
         assert rc == -1 and b"null pointer" in lib.rb_last_error()
     finally:
         lib.rb_destroy(h)
+
+
+# ---- the triangulation through radfoam::Triangulation (tests/ref_binding/hip_triangulation.cpp) -----------------------
+
+def _load_triangulation():
+    lib = C.CDLL(LIB)
+    lib.tb_last_error.restype = C.c_char_p
+    lib.tb_init.argtypes = [_P]
+    lib.tb_create.restype = _P
+    lib.tb_create.argtypes = [_P, _U32]
+    lib.tb_destroy.argtypes = [_P]
+    lib.tb_rebuild.argtypes = [_P, _P, _U32, C.c_int]
+    for name in ("tb_num_points", "tb_point_adjacency_size", "tb_num_tets"):
+        getattr(lib, name).restype = _U32
+        getattr(lib, name).argtypes = [_P]
+    for name in ("tb_permutation", "tb_point_adjacency", "tb_point_adjacency_offsets"):
+        getattr(lib, name).restype = _P
+        getattr(lib, name).argtypes = [_P]
+    return lib
+
+
+@needs_lib
+def test_triangulation_binding_compiles_against_the_reference_header():
+    """not gpu: hip_triangulation.cpp -- a radfoam::Triangulation subclass over rf_kd_order / rf_build_aabb_tree /
+    rf_delaunay_adjacency -- compiled against the reference's src/delaunay/delaunay.h and defines the factory the
+    reference declares there (Triangulation::create_triangulation, delaunay.h:41-42)."""
+    import subprocess
+    _load_triangulation()   # every tb_* entry point resolves
+    syms = subprocess.run(["nm", "-DC", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    assert "radfoam::Triangulation::create_triangulation(void const*, unsigned int)" in syms
+
+
+@needs_lib
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("RF_TEST_EXPERIMENTAL") != "1",
+                    reason="written after the round's GPU minutes were spent: RF_TEST_EXPERIMENTAL=1 runs it")
+def test_triangulation_binding_matches_the_python_path():
+    """What comes out of the reference's virtual interface (permutation, point_adjacency, offsets; rebuild with and
+    without `incremental`; the failure type) equals radfoam.Triangulation's."""
+    import radfoam
+    lib = _load_triangulation()
+    lib.tb_init(None)
+    rng = np.random.default_rng(31)
+    raw = torch.from_numpy(rng.uniform(-1, 1, size=(30000, 3)).astype(np.float32)).cuda()
+    tri = radfoam.Triangulation(raw)
+    h = lib.tb_create(raw.data_ptr(), raw.shape[0])
+    assert h, lib.tb_last_error()
+
+    def view(ptr, count):
+        out = torch.empty(count, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        C.CDLL("libamdhip64.so").hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(4 * count), 3)
+        return out.view(torch.uint32)
+
+    n = raw.shape[0]
+    assert lib.tb_num_points(h) == n and lib.tb_num_tets(h) == 0
+    e = lib.tb_point_adjacency_size(h)
+    assert e == tri.point_adjacency().numel()
+    assert torch.equal(view(lib.tb_permutation(h), n).view(torch.int32), tri.permutation().view(torch.int32))
+    assert torch.equal(view(lib.tb_point_adjacency(h), e).view(torch.int32), tri.point_adjacency().view(torch.int32))
+    assert torch.equal(view(lib.tb_point_adjacency_offsets(h), n + 1).view(torch.int32),
+                       tri.point_adjacency_offsets().view(torch.int32))
+    sorted_pts = raw[tri.permutation().to(torch.long)]
+    moved = (sorted_pts + 1e-3 * torch.randn_like(sorted_pts)).contiguous()
+    assert lib.tb_rebuild(h, moved.data_ptr(), n, 1) == 0            # incremental: no re-sort
+    assert tri.rebuild(moved, incremental=True) is False
+    e = lib.tb_point_adjacency_size(h)
+    assert torch.equal(view(lib.tb_point_adjacency(h), e).view(torch.int32), tri.point_adjacency().view(torch.int32))
+    dup = moved.clone()
+    dup[5] = dup[777]
+    assert lib.tb_rebuild(h, dup.data_ptr(), n, 0) == -1
+    assert lib.tb_last_error_is_triangulation_failed() == 1 and b"duplicate points found" in lib.tb_last_error()
+    lib.tb_destroy(h)
