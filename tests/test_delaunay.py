@@ -169,6 +169,44 @@ def test_host_failures_are_reported_not_hidden():
                 assert index[tuple(q)] in row
 
 
+def test_host_degenerate_clouds_terminate_and_say_so():
+    """Inputs a training run can stumble into (coplanar / collinear / identical points, exact lattices, a unit sphere of
+    normalised floats, denormal-sized coordinates): the star loop must end -- a lane that does not would hang the GPU --
+    and every failure must surface as a star status or an unmatched edge, never as a silently wrong list."""
+    rng = np.random.default_rng(0)
+    n = 2500
+    sphere = rng.normal(size=(n, 3))
+    sphere /= np.linalg.norm(sphere, axis=1, keepdims=True)
+    lattice = np.stack(np.meshgrid(*[np.arange(12)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    clouds = {
+        "plane": (np.c_[rng.uniform(-1, 1, size=(n, 2)), np.zeros(n)], "all_fail"),
+        "line": (np.c_[rng.uniform(-1, 1, size=n), np.zeros(n), np.zeros(n)], "all_fail"),
+        "identical": (np.ones((200, 3)), "all_fail"),
+        "duplicates": (np.repeat(rng.uniform(-1, 1, size=(n // 4, 3)), 4, axis=0), "all_fail"),
+        "unit sphere": (sphere, "exact"),
+        "tiny": (1e-30 * rng.uniform(-1, 1, size=(n, 3)), "exact"),
+        "lattice + jitter": (lattice + 1e-6 * rng.normal(size=lattice.shape), "flagged_or_exact"),
+    }
+    for name, (cloud, expect) in clouds.items():
+        pts = _kd(cloud)
+        off, adj, info = S.delaunay(pts, stride=4096)
+        rows = np.repeat(np.arange(len(off) - 1, dtype=np.int64), np.diff(off.astype(np.int64)))
+        forward = rows * (1 << 32) | adj.astype(np.int64)
+        backward = adj.astype(np.int64) * (1 << 32) | rows
+        unmatched = np.setdiff1d(forward, backward).size
+        if expect == "all_fail":
+            assert info["bad"] == len(pts), name
+            continue
+        exact = False
+        if info["bad"] == 0 and unmatched == 0:
+            off0, adj0 = foam.delaunay_csr(pts)
+            exact = np.array_equal(off, off0) and np.array_equal(adj, adj0)
+        if expect == "exact":
+            assert exact, name
+        else:
+            assert exact or info["bad"] > 0 or unmatched > 0, name
+
+
 # ---- GPU ----------------------------------------------------------------------------------------------------------------
 
 def _t(a, dev="cuda"):
