@@ -124,8 +124,8 @@ int star_host_delaunay(const float *pts, uint32_t n, const float *tree, uint32_t
 // records or the tree; stars parked in either pass go to the large instance with the hull candidates, as in the
 // default build.  tree_knn = 0: seeds from the kd-block; 24: the 24 nearest points by a tree walk.
 int star_host_delaunay_owner(const float *pts, uint32_t n, const float *tree, uint32_t depth, uint32_t knn,
-                             uint32_t tree_knn, uint32_t budget, uint32_t *rows, int stride, uint32_t *degree,
-                             uint8_t *hull, int *status, double *stats) {
+                             uint32_t tree_knn, uint32_t budget, const uint32_t *old_adj, const uint32_t *old_off,
+                             uint32_t *rows, int stride, uint32_t *degree, uint8_t *hull, int *status, double *stats) {
     if (stride < 250) return -1;
     using Small = Star<64, 124>;
     using Rec = StarRecord<64, 124>;
@@ -142,7 +142,9 @@ int star_host_delaunay_owner(const float *pts, uint32_t n, const float *tree, ui
         uint32_t seeds[64];
         int ns = 0;
         uint32_t vis = 0, in = 0;
-        if (tree_knn) {
+        if (old_adj) {   // incremental: the previous lists
+            for (uint32_t e = old_off[i]; e < old_off[i + 1] && ns < 63; ++e) seeds[ns++] = old_adj[e];
+        } else if (tree_knn) {
             ns = star_knn<24>(tr, pts, i, seeds, vis);
             nodes_knn += vis;
             vis = 0;
@@ -197,7 +199,7 @@ int star_host_delaunay_owner(const float *pts, uint32_t n, const float *tree, ui
 #pragma omp parallel for schedule(dynamic, 16) reduction(+ : bad, redone)
     for (uint32_t i = 0; i < n; ++i) {
         if (status[i] == kPending || status[i] == kOverflow) {
-            status[i] = one_star<Star<250, 496>>(pts, n, tr, second, i, knn, nullptr, nullptr, rows + (size_t)i * stride,
+            status[i] = one_star<Star<250, 496>>(pts, n, tr, second, i, knn, old_adj, old_off, rows + (size_t)i * stride,
                                                  degree, hull, vis2.data(), ins2.data());
             redone++;
         }

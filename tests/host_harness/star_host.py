@@ -39,8 +39,8 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_uint32]
         _lib.star_host_delaunay_owner.restype = C.c_int
         _lib.star_host_delaunay_owner.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
-                                                  C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                  C.c_void_p]
+                                                  C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -96,7 +96,8 @@ def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250, gho
                                                        hull=hull, degree=degree)
 
 
-def delaunay_owner(points: np.ndarray, tree_knn: int = 0, knn: int = 12, budget: int = 512, stride: int = 250):
+def delaunay_owner(points: np.ndarray, tree_knn: int = 0, knn: int = 12, budget: int = 512, stride: int = 250,
+                   old=None):
     """(offsets, adjacency, info) through the experimental two-pass build (every tetrahedron certified once)."""
     pts = np.ascontiguousarray(points, dtype=np.float32)
     n = pts.shape[0]
@@ -107,7 +108,12 @@ def delaunay_owner(points: np.ndarray, tree_knn: int = 0, knn: int = 12, budget:
     hull = np.zeros(n, dtype=np.uint8)
     status = np.zeros(n, dtype=np.int32)
     stats = np.zeros(6)
+    oa = oo = None
+    if old is not None:
+        oo = np.ascontiguousarray(old[0], dtype=np.uint32)
+        oa = np.ascontiguousarray(old[1], dtype=np.uint32)
     bad = lib().star_host_delaunay_owner(pts.ctypes.data, n, tree.ctypes.data, depth, knn, tree_knn, budget,
+                                         None if oa is None else oa.ctypes.data, None if oo is None else oo.ctypes.data,
                                          rows.ctypes.data, stride, degree.ctypes.data, hull.ctypes.data,
                                          status.ctypes.data, stats.ctypes.data)
     offsets = np.zeros(n + 1, dtype=np.int64)
