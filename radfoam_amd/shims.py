@@ -112,9 +112,8 @@ class Triangulation:
 
 def build_aabb_tree(points: torch.Tensor) -> torch.Tensor:
     """Tensor of the reference's shape [pow2_round_up(N), 2, 3].  CUDA float32 points: the reference's
-    tree itself (bit-identical boxes; the GPU triangulation searches it).  CPU tensors: only ``nn`` would
-    consume it, and this package's ``nn`` is an exact brute-force search, so that tensor just carries the
-    global bounding box (a valid, if useless, bound for every node).
+    tree itself (bit-identical boxes; the GPU triangulation searches it).  CPU tensors: the same tree, by torch
+    pooling (only ``nn`` would consume it, and this package's ``nn`` is an exact brute-force search).
     """
     if points.size(-1) != 3:
         raise RuntimeError("points must have 3 as the last dimension")
@@ -123,11 +122,26 @@ def build_aabb_tree(points: torch.Tensor) -> torch.Tensor:
     if points.is_cuda and points.dtype == torch.float32:
         from . import triangulation
         return triangulation.build_aabb_tree(points)   # the reference's tree, HIP (rf_build_aabb_tree)
+    # CPU tensors: the same tree (build_leaves_kernel / build_tree_kernel, aabb_tree.cu:192-283) by pooling: level d
+    # (2^d nodes) starts at node 2^depth - 2^(d+1); the deepest level pairs the points, indices past N repeat the last
+    # point; the last entry is never written (left zero)
     n = points.size(0)
-    lo = points.min(dim=0).values
-    hi = points.max(dim=0).values
-    box = torch.stack([lo, hi], dim=0)
-    return box.unsqueeze(0).expand(_foam.pow2_round_up(n), 2, 3).contiguous()
+    p2 = _foam.pow2_round_up(n)
+    tree = torch.zeros((p2, 2, 3), dtype=points.dtype, device=points.device)
+    if p2 < 2:
+        return tree
+    pad = torch.cat([points.detach(), points.detach()[-1:].expand(p2 - n, 3)], dim=0)
+    lo = torch.minimum(pad[0::2], pad[1::2])
+    hi = torch.maximum(pad[0::2], pad[1::2])
+    depth = p2.bit_length() - 1
+    for d in range(depth - 1, -1, -1):
+        start = p2 - (1 << (d + 1))
+        tree[start:start + (1 << d), 0] = lo
+        tree[start:start + (1 << d), 1] = hi
+        if d:
+            lo = torch.minimum(lo[0::2], lo[1::2])
+            hi = torch.maximum(hi[0::2], hi[1::2])
+    return tree
 
 
 def nn(points: torch.Tensor, tree: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:

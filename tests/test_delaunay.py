@@ -169,6 +169,18 @@ def test_host_failures_are_reported_not_hidden():
                 assert index[tuple(q)] in row
 
 
+@pytest.mark.parametrize("n", [33, 1000, 4096, 5001])
+def test_cpu_aabb_tree_is_the_reference_tree(n):
+    """radfoam.build_aabb_tree on CPU tensors (torch pooling) = the numpy restatement of build_aabb_tree
+    (src/aabb_tree/aabb_tree.cu:192-283) the GPU kernel is checked against."""
+    import torch
+    import radfoam
+    pts = _kd(np.random.default_rng(n).normal(size=(n, 3)))
+    tree = radfoam.build_aabb_tree(torch.from_numpy(pts)).numpy()
+    ref = S.aabb_tree(pts)
+    assert tree.shape == ref.shape and np.array_equal(tree[:-1].view(np.uint32), ref[:-1].view(np.uint32))
+
+
 def test_host_degenerate_clouds_terminate_and_say_so():
     """Inputs a training run can stumble into (coplanar / collinear / identical points, exact lattices, a unit sphere of
     normalised floats, denormal-sized coordinates): the star loop must end -- a lane that does not would hang the GPU --
