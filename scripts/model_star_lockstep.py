@@ -30,3 +30,37 @@ for width, eff in ((8, 3.0), (16, 4.5)):
     S_ = (steps * mask).reshape(-1, width, 64 // width, cap)    # [wave, round, concurrent star, query]
     cost = S_.max(2).sum(2).sum(1)                              # per round lockstep over concurrent stars, rounds add
     print("sub-wave width %d (assumed %.1f nodes per step): steps per 64 stars %.0f (now %.0f)" % (width, eff, cost.mean(), lockstep.mean()))
+
+# ---- persistent waves: a lane that finishes its star gets the next point of the wave's queue; refills happen when at
+# least K lanes are idle (seeding a star is a long stretch only the refilled lanes execute), SEED node-steps each.
+def persistent(K, SEED=400, chunk=1024):
+    """steps a wave needs for `chunk` stars taken from a queue, per 64 stars"""
+    total = 0.0
+    stars = [(nodes[k][: lens[k]]) for k in range(count)]
+    for w0 in range(0, count - chunk + 1, chunk):
+        queue = list(range(w0, w0 + chunk))
+        lane_star = [None] * 64          # remaining query lengths of the lane's star
+        steps = 0.0
+        while True:
+            idle = [l for l in range(64) if lane_star[l] is None or len(lane_star[l]) == 0]
+            if queue and (len(idle) >= K or len(idle) == 64):
+                for l in idle:
+                    if not queue:
+                        break
+                    lane_star[l] = list(stars[queue.pop()])
+                steps += SEED
+            active = [l for l in range(64) if lane_star[l]]
+            if not active:
+                if not queue:
+                    break
+                continue
+            steps += max(lane_star[l][0] for l in active)     # one query of every active lane, in lockstep
+            for l in active:
+                lane_star[l].pop(0)
+        total += steps
+    return total / ((count // chunk) * chunk / 64.0)
+
+
+print("today (one star per lane, query-synchronous): %.0f node-steps per 64 stars" % lockstep.mean())
+for K in (1, 8, 16, 32):
+    print("persistent waves, refill when >= %2d lanes are idle (400 node-steps per refill): %.0f" % (K, persistent(K)))
