@@ -74,6 +74,25 @@ def lib():
     return _lib
 
 
+class scan_mode:
+    """``with O.scan_mode("reference"):`` -- the oracle finds a cell's exit the way the reference writes it
+    (every face divided, running minimum of the rounded quotients, (P + o/2) - O) instead of by the canonical
+    cross-multiplied tournament the HIP kernels implement.  The independent check that the canonical arithmetic
+    did not drift: both modes must agree up to exact-tie flips (tests/test_oracle.py)."""
+
+    def __init__(self, mode):
+        self.mode = {"canonical": 0, "reference": 1}[mode]
+
+    def __enter__(self):
+        self.prev = lib().rfo_get_scan_mode()
+        lib().rfo_set_scan_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        lib().rfo_set_scan_mode(self.prev)
+        return False
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 

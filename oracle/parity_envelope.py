@@ -1,0 +1,186 @@
+"""Parity against the reference SOURCE at the BASELINE configurations.  TEST INFRASTRUCTURE ONLY.
+
+The north star states its tolerance (1e-4 RGB, 1e-3 gradients) against the reference renderer.  What can run here is
+the reference's kernel source text compiled for the CPU (oracle/_ref/libref.so, oracle/Makefile.ref) -- and that text
+does not define its fp32 results to the last bit: nvcc contracts a*b+c into FMAs by default, this build does not.  So
+the same source is compiled twice (libref.so: no contraction; libref_fma.so: -ffp-contract=fast -mfma, every a*b+c the
+compiler sees fused) and three evaluations are compared on every STRIDE-th row and column of a BASELINE frame:
+
+    oracle   the canonical arithmetic of oracle/rf_oracle.c == the HIP kernels, bit for bit (tests/test_gpu_parity.py,
+             bench.py's whole-frame check)
+    ref      the reference source, no contraction
+    ref_fma  the reference source, contracted
+
+For each pair: rays whose walk takes another path (different num_intersections -- a near-tie between two exit faces
+decided the other way: a cell inserted or skipped), rays with |d rgba| above 1e-4 / 1e-5, and the relative L2 distance
+of points_grad / attr_grad: overall, and split by linearity (a gradient is a sum over rays) into the part carried by
+the rays of the pair that take the same path and the part carried by the flipped rays (a second backward over just
+those).  The pair (ref_fma, ref) is the reference's OWN envelope: what its two legitimate builds disagree about.
+
+What the numbers say (profiles/r03/parity_baseline_scale.json): 0.05-0.2 % of the rays pass a Voronoi edge so closely
+that the two candidate exits agree to an ulp, and any change of rounding decides them the other way.  Such a ray keeps
+its colour (1e-5 typically, 2e-4 at worst) but deposits its point gradient in other cells, so the OVERALL gradient
+distance is the gradient of the one or two heaviest flipped rays (per-ray norms are heavy-tailed: median 10, max 85 on
+config 2, against 8.3e3 for the whole sample) -- 1.2e-3 between the reference's own two builds, above the north
+star's 1e-3 by itself.  A factor between two such figures compares two outliers, not two implementations.  The bar
+(tests/test_reference_source.py) is therefore: no more flipped rays than 1.5x the reference's own; no more rays
+beyond 1e-4 in rgba than 1.5x its own (floor 2), none beyond 3e-4; on the rays that take the same path, gradients
+within 2e-4 of the nearer of the two builds (the oracle spells its FMAs out, so it sits with the contracted build: 3e-7
+on attr_grad where the uncontracted build is 1.9e-3 away from both); overall gradients within 1e-2.  Any further
+change of the canonical arithmetic has to pass this before the goldens.
+
+    python -m oracle.parity_envelope [c2] [north-star] [--stride 6] [--out profiles/r03/parity_baseline_scale.json]
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+CONFIGS = {
+    # name: (points, sh degree, foam seed)   -- BASELINE.json configs[1] and the north-star point
+    "c2": (500_000, 2, 1),
+    "north-star": (2_000_000, 2, 5),
+}
+
+
+def _rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _pair(fa, fb, ba, bb, flipped_a, flipped_b):
+    d = np.abs(np.asarray(fa["rgba"], np.float64) - np.asarray(fb["rgba"], np.float64)).max(axis=-1)
+    rec = {
+        "rays_on_another_path": int((fa["num_intersections"] != fb["num_intersections"]).sum()),
+        "rays_drgba_gt_1e-4": int((d > 1e-4).sum()),
+        "rays_drgba_gt_1e-5": int((d > 1e-5).sum()),
+        "max_drgba": float(d.max()),
+    }
+    for k in ("points_grad", "attr_grad"):
+        ref = np.asarray(bb[k], np.float64)
+        total = np.asarray(ba[k], np.float64) - ref
+        flipped = np.asarray(flipped_a[k], np.float64) - np.asarray(flipped_b[k], np.float64)
+        scale = max(np.linalg.norm(ref), 1e-300)
+        rec[k + "_rel_l2"] = float(np.linalg.norm(total) / scale)
+        rec["same_path_" + k + "_rel_l2"] = float(np.linalg.norm(total - flipped) / scale)   # linearity
+        rec["flipped_rays_" + k + "_rel_l2"] = float(np.linalg.norm(flipped) / scale)
+    return rec
+
+
+def measure(fm, sh_degree, width=1920, height=1080, stride=6, grad_seed=11, with_quotient_mode=True):
+    """The three evaluations on rows/columns 0, stride, 2*stride, ... of the width x height frame of the SURVEY 8(d)
+    camera; returns the record described in the module docstring."""
+    from oracle import oracle as O
+    from oracle import refsrc as Rf
+    from radfoam_amd import foam
+
+    cam = foam.default_camera(width, height)
+    rays = np.ascontiguousarray(foam.camera_rays(cam)[::stride, ::stride])
+    start = np.uint32(foam.nearest_point(fm["points"], cam["position"]))
+    rng = np.random.default_rng(grad_seed)
+    g = rng.normal(size=rays.shape[:-1] + (4,)).astype(np.float32)
+    args = (sh_degree, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+
+    t = time.time()
+
+    def run(name, r, gg, rgba=None):
+        """(forward, backward) of evaluation `name` over rays r"""
+        def both(fwd_fn, bwd_fn):
+            f = fwd_fn(*args, r, start)
+            return f, bwd_fn(*args, r, start, f["rgba"] if rgba is None else rgba, gg)
+        if name in ("ref", "ref_fma"):
+            with Rf.variant("fma" if name == "ref_fma" else "plain"):
+                return both(Rf.trace_forward, Rf.trace_backward)
+        if name == "oracle_quotient_scan":
+            with O.scan_mode("reference"):
+                return both(O.trace_forward, O.trace_backward)
+        return both(O.trace_forward, O.trace_backward)
+
+    names = ["ref", "ref_fma", "oracle"] + (["oracle_quotient_scan"] if with_quotient_mode else [])
+    fwd, bwd = {}, {}
+    for name in names:
+        fwd[name], bwd[name] = run(name, rays, g)
+
+    def pair(a, b):
+        flipped = (fwd[a]["num_intersections"] != fwd[b]["num_intersections"]).reshape(-1)
+        r, gg = rays.reshape(-1, 6)[flipped], g.reshape(-1, 4)[flipped]
+        if r.shape[0]:
+            _, fa = run(a, r, gg)
+            _, fb = run(b, r, gg)
+        else:
+            fa = fb = {k: np.zeros_like(bwd[a][k]) for k in ("points_grad", "attr_grad")}
+        return _pair(fwd[a], fwd[b], bwd[a], bwd[b], fa, fb)
+
+    rec = {
+        "points": int(fm["points"].shape[0]), "sh_degree": sh_degree, "frame": [height, width], "stride": stride,
+        "rays": int(rays.shape[0] * rays.shape[1]),
+        "mean_cells_per_ray": float(fwd["ref"]["num_intersections"].mean()),
+        "oracle_vs_ref": pair("oracle", "ref"),
+        "oracle_vs_ref_fma": pair("oracle", "ref_fma"),
+        "ref_fma_vs_ref": pair("ref_fma", "ref"),
+    }
+    if with_quotient_mode:
+        rec["oracle_quotient_scan_vs_ref"] = pair("oracle_quotient_scan", "ref")
+        rec["oracle_vs_oracle_quotient_scan"] = pair("oracle", "oracle_quotient_scan")
+    rec["seconds"] = round(time.time() - t, 1)
+    return rec
+
+
+def check(rec):
+    """The bar (module docstring): the oracle is inside the reference's own envelope.  Returns the list of violations
+    (empty = pass)."""
+    bad = []
+    own = rec["ref_fma_vs_ref"]
+    for other in ("oracle_vs_ref", "oracle_vs_ref_fma"):
+        o = rec[other]
+        if o["rays_on_another_path"] > 1.5 * max(own["rays_on_another_path"], 8):
+            bad.append((other, "rays_on_another_path", o["rays_on_another_path"], own["rays_on_another_path"]))
+        if o["rays_drgba_gt_1e-4"] > 1.5 * max(own["rays_drgba_gt_1e-4"], 2):
+            bad.append((other, "rays_drgba_gt_1e-4", o["rays_drgba_gt_1e-4"], own["rays_drgba_gt_1e-4"]))
+        if not o["max_drgba"] < 3e-4:
+            bad.append((other, "max_drgba", o["max_drgba"], 3e-4))
+    for k in ("points_grad", "attr_grad"):
+        same = min(rec["oracle_vs_ref"]["same_path_" + k + "_rel_l2"],
+                   rec["oracle_vs_ref_fma"]["same_path_" + k + "_rel_l2"])
+        if not same < 2e-4:
+            bad.append(("oracle_vs_nearer_build", "same_path_" + k + "_rel_l2", same, 2e-4))
+        overall = min(rec["oracle_vs_ref"][k + "_rel_l2"], rec["oracle_vs_ref_fma"][k + "_rel_l2"])
+        if not overall < 1e-2:
+            bad.append(("oracle_vs_nearer_build", k + "_rel_l2", overall, 1e-2))
+    return bad
+
+
+def load_foam(name, build_if_missing=True):
+    from radfoam_amd import foam
+
+    n, d, seed = CONFIGS[name]
+    path = os.path.join(foam.default_cache_dir(), f"foam_n{n}_s{seed}.npz")
+    if not os.path.exists(path) and not build_if_missing:
+        return None, d
+    return foam.make_synthetic_foam(n, d, seed, cache_dir=foam.default_cache_dir()), d
+
+
+def main(argv):
+    names = [a for a in argv if a in CONFIGS] or list(CONFIGS)
+    stride = int(argv[argv.index("--stride") + 1]) if "--stride" in argv else 6
+    out = argv[argv.index("--out") + 1] if "--out" in argv else None
+    result = {}
+    for name in names:
+        fm, d = load_foam(name)
+        rec = measure(fm, d, stride=stride)
+        rec["violations"] = check(rec)
+        result[name] = rec
+        print(name, json.dumps(rec, indent=1))
+    if out:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        with open(out, "w") as f:
+            json.dump(result, f, indent=1)
+    return 0 if all(not r["violations"] for r in result.values()) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

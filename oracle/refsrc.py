@@ -13,12 +13,39 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_ref", "libref.so")
+#: the same source text compiled with -ffp-contract=fast -mfma: every a*b+c contracted, as nvcc does by default
+LIB_PATH_FMA = os.path.join(_HERE, "_ref", "libref_fma.so")
 REFERENCE = "/root/reference"
 _lib = None
+_libs = {}
+
+
+class variant:
+    """``with refsrc.variant("fma"):`` -- calls inside go to libref_fma.so (the reference source with FMA
+    contraction) instead of libref.so (no contraction).  The gap between the two builds is the reference's own
+    floating-point indeterminacy (oracle/parity_envelope.py)."""
+
+    def __init__(self, name):
+        self.path = {"plain": LIB_PATH, "fma": LIB_PATH_FMA}[name]
+
+    def __enter__(self):
+        global _lib
+        self.prev = _lib
+        lib()   # liboracle.so + the build
+        if self.path not in _libs:
+            _libs[self.path] = C.CDLL(self.path)
+        _lib = _libs[self.path]
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
+        return False
 
 
 def available() -> bool:
-    return os.path.exists(LIB_PATH) or os.path.isdir(os.path.join(REFERENCE, "src", "tracing"))
+    return (os.path.exists(LIB_PATH) and os.path.exists(LIB_PATH_FMA)) or \
+        os.path.isdir(os.path.join(REFERENCE, "src", "tracing"))
 
 
 def build() -> str:
@@ -34,12 +61,12 @@ def build() -> str:
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        if not (os.path.exists(LIB_PATH) and os.path.exists(LIB_PATH_FMA)):
             build()
         from . import oracle as O
 
         O.lib()  # liboracle.so provides the half conversions the shim uses
-        _lib = C.CDLL(LIB_PATH)
+        _lib = _libs.setdefault(LIB_PATH, C.CDLL(LIB_PATH))
     return _lib
 
 

@@ -64,6 +64,13 @@ typedef struct {
     uint64_t segments_lit;    /* ... with density > 1e-6 (SH row needed)     */
 } rfo_stats;
 
+/* How the nearest exit of a cell is found: 0 = canonical (cross-multiplied pair tournament, one divide per cell:
+ * what the HIP kernels implement and are compared bit for bit against), 1 = the reference's own order (every face
+ * divided, running minimum of rounded quotients, v = (P + o/2) - O).  Process-global, set by the tests only. */
+static int rfo_scan_mode = 0;
+void rfo_set_scan_mode(int mode) { rfo_scan_mode = mode == 1 ? 1 : 0; }
+int rfo_get_scan_mode(void) { return rfo_scan_mode; }
+
 /* ------------------------------------------------------------------------------------ */
 /* half <-> float, software, RNE (== __float2half / __half2float)                        */
 

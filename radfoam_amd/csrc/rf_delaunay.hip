@@ -153,11 +153,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(
     uint32_t *__restrict__ degree, uint32_t *__restrict__ overflow_list, uint32_t *__restrict__ hull_list,
     uint32_t budget, StarCounters *__restrict__ counters) {
     __shared__ float block_pts[64 * 3];
-    const uint32_t block_first = blockIdx.x * 64u;
-    const uint32_t block_count = n - block_first < 64u ? n - block_first : 64u;
+    // candidates of a lane without a previous list: the block's own points (a short last block: the last 64 points)
+    uint32_t block_first, block_count;
+    star::seed_window(n, blockIdx.x * 64u, block_first, block_count);
     for (uint32_t k = threadIdx.x; k < 3 * block_count; k += 64) block_pts[k] = pts[3 * (size_t)block_first + k];
     __syncthreads();
-    const uint32_t i = block_first + threadIdx.x;
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= n) return;
 
     SmallStar s;
@@ -241,11 +242,12 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_owner_pass1_kerne
     uint32_t *__restrict__ rows, uint32_t *__restrict__ degree, uint32_t *__restrict__ overflow_list,
     uint32_t *__restrict__ hull_list, uint32_t budget, StarCounters *__restrict__ counters) {
     __shared__ float block_pts[64 * 3];
-    const uint32_t block_first = blockIdx.x * 64u;
-    const uint32_t block_count = n - block_first < 64u ? n - block_first : 64u;
+    // candidates of a lane without a previous list: the block's own points (a short last block: the last 64 points)
+    uint32_t block_first, block_count;
+    star::seed_window(n, blockIdx.x * 64u, block_first, block_count);
     for (uint32_t k = threadIdx.x; k < 3 * block_count; k += 64) block_pts[k] = pts[3 * (size_t)block_first + k];
     __syncthreads();
-    const uint32_t i = block_first + threadIdx.x;
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
     if (i >= n) return;
     SmallStar s;
     star::star_reset(s, i, pts + 3 * (size_t)i);
@@ -425,8 +427,8 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
     uint32_t visited = 0, inserted = 0;
     if (tid == 0) {
         star::star_reset(s, i, pts + 3 * (size_t)i);
-        const uint32_t block_first = i & ~63u;
-        const uint32_t block_count = n - block_first < 64u ? n - block_first : 64u;
+        uint32_t block_first, block_count;
+        star::seed_window(n, i, block_first, block_count);
         int ns = (int)degree[i];   // the link vertices the first pass got to
         if (ns >= 3) {
             for (int k = 0; k < ns; ++k) seeds[k] = rows[(size_t)i * kSmallV + k];
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(64 * kHugeWaves) void delaunay_star_huge_kernel(
     __shared__ int ok;
     const uint32_t b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     const uint32_t total = counters->huge;
-    if (b == 0 && tid == 0 && total > (uint32_t)kHugeStars) atomicAdd(&counters->failed[star::kOverflow], total - kHugeStars);
+    // (hubs beyond kHugeStars were already counted as failed by the second pass, which found no slot for them)
     if (b >= total || b >= (uint32_t)kHugeStars) return;
     const uint32_t w = huge_list[b], i = overflow_list[w];
     HugeStar &s = arena[b];

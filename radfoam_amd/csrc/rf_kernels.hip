@@ -232,52 +232,132 @@ struct __attribute__((aligned(8))) GeoZ {
 // expanded divides.
 // The winner is tracked relative to the block being scanned (`rel`, inline constants 0..3) and rebased once per
 // iteration, instead of materialising k+j per face.
+// RF_SCAN_PIPE (build knob; the arithmetic -- hence every result bit -- is the same in all of them):
+//   0  every iteration loads its own block and waits for it;
+//   2  the first block of a cell arrives as an argument: the walk requests it at hop time, from the link of the face
+//      just crossed, together with the next cell's record, so that it arrives under the compositing of the segment
+//      instead of being waited for at the top of the next scan; the remaining blocks as in 0;
+//   3  as 2, and the remaining blocks are software-pipelined: block k+1 is requested before block k is computed and
+//      waited for after it.  Written with inline-asm loads and an explicit s_waitcnt: left to itself the optimiser
+//      rotates a source-level pipeline back into load-wait-compute (it proves the prefetched address equal to the
+//      next iteration's block).  Compiler-generated waits stay correct next to the asm loads: memory operations
+//      return in order, so an extra outstanding request can only make a compiler wait longer, never shorter.
+#ifndef RF_SCAN_PIPE
+#define RF_SCAN_PIPE 0
+#endif
+
+__device__ __forceinline__ void load_geo_block(const uint32_t *src, GeoXY &A, GeoZ &B) {
+    A = *reinterpret_cast<const GeoXY *>(src);
+    B = *reinterpret_cast<const GeoZ *>(src + 4);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// running state of a scan: best exit so far as the fraction best.y / best.x (inf/1 loses against any valid face) and
+// its position relative to the current block
+struct ScanState {
+    v2f best;
+    int rel;
+};
+
+// the four faces of one block against the running best
+__device__ __forceinline__ void scan_block(ScanState &S, const GeoXY &A, const GeoZ &B, v2f C2x, v2f C2y, v2f C2z,
+                                           v2f d2x, v2f d2y, v2f d2z) {
+    const v2f half2 = {0.5f, 0.5f};
+    S.rel -= 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t wx = h ? A.x23 : A.x01, wy = h ? A.y23 : A.y01, wz = h ? B.z23 : B.z01;
+        const v2f ox = {half_lo(wx), half_hi(wx)};
+        const v2f oy = {half_lo(wy), half_hi(wy)};
+        const v2f oz = {half_lo(wz), half_hi(wz)};
+        // dp = fma(ox,dx, fma(oy,dy, oz*dz))
+        const v2f dpp = fma2(ox, d2x, fma2(oy, d2y, oz * d2z));
+        // v = (P - O) + o/2 ; num = fma(vx,ox, fma(vy,oy, vz*oz))
+        const v2f vx = fma2(ox, half2, C2x);
+        const v2f vy = fma2(oy, half2, C2y);
+        const v2f vz = fma2(oz, half2, C2z);
+        const v2f num = fma2(vx, ox, fma2(vy, oy, vz * oz));
+        // the nearer face of the pair (the first on a tie, or when the second is no exit) ...
+        const v2f c = __builtin_shufflevector(num, num, 1, 0) * dpp;    // {num1*dp0, num0*dp1}
+        // (bitwise, not short-circuit, logic on the predicates: everything is computed for both faces anyway and
+        // the compiler must not turn the selection into branches)
+        const bool v0 = dpp.x > 0.0f, v1 = dpp.y > 0.0f, lt10 = c.x < c.y;
+        const bool w1 = v1 & (!v0 | lt10);
+        const v2f cand = {w1 ? num.y : num.x, w1 ? dpp.y : dpp.x};      // (num, dp) of the pair's winner
+        // ... against the running best, kept as the adjacent pair (db, nb): one packed multiply forms both products
+        const v2f ab = cand * S.best;                                    // {num_w*db, dp_w*nb}
+        const bool take = (w1 | v0) & (ab.x < ab.y);
+        S.best.x = take ? cand.y : S.best.x;
+        S.best.y = take ? cand.x : S.best.y;
+        S.rel = take ? (w1 ? 2 * h + 1 : 2 * h) : S.rel;
+    }
+}
+
 __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t cnt, float Px, float Py,
                                                  float Pz, float Ox, float Oy, float Oz, float dx,
-                                                 float dy, float dz) {
+                                                 float dy, float dz, const GeoXY *A0 = nullptr,
+                                                 const GeoZ *B0 = nullptr) {
     ScanResult r;
     constexpr int kUnset = -0x40000000;
-    int rel = kUnset;
-    v2f best = {1.0f, __builtin_inff()};   // running best as the fraction best.y / best.x = nb / db: inf/1 loses
-                                           // against any valid face
+    ScanState S;
+    S.rel = kUnset;
+    S.best = {1.0f, __builtin_inff()};
     const float cx = Px - Ox, cy = Py - Oy, cz = Pz - Oz;   // once per cell, not per face
     const v2f C2x = {cx, cx}, C2y = {cy, cy}, C2z = {cz, cz};
     const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
-    const v2f half2 = {0.5f, 0.5f};
     const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
-    for (uint32_t k = 0; k < cnt; k += 4) {
-        const GeoXY A = *reinterpret_cast<const GeoXY *>(src);
-        const GeoZ B = *reinterpret_cast<const GeoZ *>(src + 4);
-        src += 6;
-        rel -= 4;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t wx = h ? A.x23 : A.x01, wy = h ? A.y23 : A.y01, wz = h ? B.z23 : B.z01;
-            const v2f ox = {half_lo(wx), half_hi(wx)};
-            const v2f oy = {half_lo(wy), half_hi(wy)};
-            const v2f oz = {half_lo(wz), half_hi(wz)};
-            // dp = fma(ox,dx, fma(oy,dy, oz*dz))
-            const v2f dpp = fma2(ox, d2x, fma2(oy, d2y, oz * d2z));
-            // v = (P - O) + o/2 ; num = fma(vx,ox, fma(vy,oy, vz*oz))
-            const v2f vx = fma2(ox, half2, C2x);
-            const v2f vy = fma2(oy, half2, C2y);
-            const v2f vz = fma2(oz, half2, C2z);
-            const v2f num = fma2(vx, ox, fma2(vy, oy, vz * oz));
-            // the nearer face of the pair (the first on a tie, or when the second is no exit) ...
-            const v2f c = __builtin_shufflevector(num, num, 1, 0) * dpp;    // {num1*dp0, num0*dp1}
-            // (bitwise, not short-circuit, logic on the predicates: everything is computed for both faces anyway and
-            // the compiler must not turn the selection into branches)
-            const bool v0 = dpp.x > 0.0f, v1 = dpp.y > 0.0f, lt10 = c.x < c.y;
-            const bool w1 = v1 & (!v0 | lt10);
-            const v2f cand = {w1 ? num.y : num.x, w1 ? dpp.y : dpp.x};      // (num, dp) of the pair's winner
-            // ... against the running best, kept as the adjacent pair (db, nb): one packed multiply forms both products
-            const v2f ab = cand * best;                                      // {num_w*db, dp_w*nb}
-            const bool take = (w1 | v0) & (ab.x < ab.y);
-            best.x = take ? cand.y : best.x;
-            best.y = take ? cand.x : best.y;
-            rel = take ? (w1 ? 2 * h + 1 : 2 * h) : rel;
+#if RF_SCAN_PIPE == 3
+    if (A0 && cnt != 0u) {
+        GeoXY A = *A0;
+        GeoZ B = *B0;
+        for (uint32_t k = 0; k < cnt; k += 4) {
+            // request block k+1 (the last iteration of a lane re-requests its own block: an L1 hit whose result is
+            // not used -- a predicated request would cost a branch per iteration) ...
+            const uint32_t *nsrc = k + 4u < cnt ? src + 6 : src;
+            u32x4 na;
+            u32x2 nb;
+            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:16"
+                         : "=&v"(na), "=&v"(nb)
+                         : "v"(nsrc)
+                         : "memory");
+            src += 6;
+            // ... compute block k from registers ...
+            scan_block(S, A, B, C2x, C2y, C2z, d2x, d2y, d2z);
+            // ... and only now wait for block k+1
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(na), "+v"(nb)::"memory");
+            A.x01 = na.x;
+            A.x23 = na.y;
+            A.y01 = na.z;
+            A.y23 = na.w;
+            B.z01 = nb.x;
+            B.z23 = nb.y;
+        }
+    } else
+#elif RF_SCAN_PIPE == 2
+    if (A0 && cnt != 0u) {
+        scan_block(S, *A0, *B0, C2x, C2y, C2z, d2x, d2y, d2z);
+        for (uint32_t k = 4; k < cnt; k += 4) {
+            src += 6;
+            GeoXY A;
+            GeoZ B;
+            load_geo_block(src, A, B);
+            scan_block(S, A, B, C2x, C2y, C2z, d2x, d2y, d2z);
+        }
+    } else
+#endif
+    {
+        for (uint32_t k = 0; k < cnt; k += 4) {
+            GeoXY A;
+            GeoZ B;
+            load_geo_block(src, A, B);
+            src += 6;
+            scan_block(S, A, B, C2x, C2y, C2z, d2x, d2y, d2z);
         }
     }
+    const int rel = S.rel;
+    const v2f best = S.best;
     // after a lane's last iteration its block base is cnt - 4
     const bool found = rel > kUnset / 2;
     r.k = found ? (cnt - 4u) + (uint32_t)rel : kNone;
@@ -483,6 +563,11 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
     }
     uint32_t wave_steps = 0;
     uint32_t hops = 0;
+#if RF_SCAN_PIPE >= 2
+    GeoXY gA{};
+    GeoZ gB{};
+    if (alive && cnt != 0u) load_geo_block(reinterpret_cast<const uint32_t *>(fv.geo + (size_t)nb * 3u), gA, gB);
+#endif
     while (ballot(alive) != 0ull) {
         wave_steps++;
         if (alive) {
@@ -493,7 +578,11 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
         sr.t1 = __builtin_inff();
         sr.k = kNone;
         if (alive) {
+#if RF_SCAN_PIPE >= 2
+            sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, &gA, &gB);
+#else
             sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
+#endif
             if (want_stats) {
                 st_cells++;
                 st_faces += fv.offsets[cur + 1] - fv.offsets[cur];
@@ -509,6 +598,11 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
             nnb = link.first;
             ncnt = link.count;
             nhead = fv.cells[nxt];
+#if RF_SCAN_PIPE >= 2
+            // the next cell's first face block, requested now: it arrives under the compositing below instead of
+            // being waited for at the top of the next scan (every cell has at least one block)
+            load_geo_block(reinterpret_cast<const uint32_t *>(fv.geo + (size_t)nnb * 3u), gA, gB);
+#endif
             if constexpr (!BENCH) {
                 // trail: the cell each hop enters, for trace_backward to replay
                 if (p.trail) {

@@ -46,6 +46,20 @@
 namespace rf {
 namespace star {
 
+// The points a star's first candidates come from when it has no previous neighbour list: its 64-point block of the
+// kd-order.  The last block of a cloud may hold one, two or three points (n % 64 in 1..3) -- fewer than a first
+// tetrahedron needs --, so a short last block takes the LAST 64 points of the cloud instead (n >= 32 always; below 64
+// points the one block is the cloud).  Shared by the kernels and the host harness.
+RF_STAR_FN void seed_window(uint32_t n, uint32_t i, uint32_t &first, uint32_t &count) {
+    first = i & ~63u;
+    count = n - first < 64u ? n - first : 64u;
+    if (count < 64u && n >= 64u) {
+        first = n - 64u;
+        count = 64u;
+    }
+}
+
+
 constexpr uint32_t kInfinity = 0xFFFFFFFFu;   // global id of the vertex at infinity; also "no point"
 constexpr int kLeafBits = 2;                  // the search tests buckets of 4 consecutive points directly
 
@@ -172,8 +186,14 @@ RF_STAR_FN void decompose(float f, int32_t &m, int32_t &e) {
     m = (u >> 31) ? -frac : frac;
 }
 
-// `count` coordinates onto one integer grid (62 bits; coordinates more than 2^38 times finer than the coarsest one
-// of the same predicate are snapped to the grid -- far below anything a float32 point cloud resolves)
+// `count` coordinates onto one integer grid (62 bits).  LIMIT OF THE "EXACT" PATH: a coordinate whose last bit lies
+// more than 38 binary places below the last bit of the coarsest coordinate of the SAME predicate is snapped to that
+// predicate's grid (truncated) -- e.g. a point at 1e-9 tested together with points around 1e3.  For such inputs the
+// predicates are exact for the snapped coordinates only, and because the grid depends on which points share the
+// predicate, two stars may sign the same configuration differently; that surfaces as unmatched edges in the symmetry
+// check (TriangulationFailedError), never as a silently wrong list.  A float32 foam whose coordinates span fewer than
+// 38 + 24 binary orders of magnitude (every scene the tracer can render: its fp16 face offsets need far less) never
+// gets there.  Widening Big to the 277-bit exponent spread of fp32 would remove the limit at ~3x the rare path's cost.
 RF_STAR_NOINLINE void to_grid(const float *c, int count, int64_t *out) {
     int32_t emax = -100000, emin = 100000;
     RF_STAR_NOUNROLL

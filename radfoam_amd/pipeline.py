@@ -177,10 +177,10 @@ class Pipeline:
         #: trace_forward records the cell every hop enters so that a trace_backward call on the same
         #: inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).  Costs
         #: trail_steps * 4 bytes per ray of HBM (2.1 GB for a 1080p frame at 256 steps), so:
-        #:   "auto" (default)  record only when a backward can follow: points or attributes require
-        #:                     grad (inside TraceRays.forward -- the reference's operator included --
-        #:                     the inputs still carry requires_grad); evaluation / no-grad renders
-        #:                     neither allocate nor write a trail;
+        #:   "auto" (default)  record only when a backward can follow (see _wants_trail: the computed
+        #:                     attributes require grad, or the points do and grad mode is on);
+        #:                     evaluation / no-grad renders -- RadFoamScene's included, which passes its
+        #:                     nn.Parameter points regardless -- neither allocate nor write a trail;
         #:   True / False      always / never (callers that drive trace_backward by hand, like
         #:                     bench.py, set True).
         self.record_trail = "auto"
@@ -207,8 +207,15 @@ class Pipeline:
         self._order = None
 
     def _wants_trail(self, points, attributes) -> bool:
+        """"auto": will a trace_backward follow this forward?  Inside an autograd.Function.forward grad mode is off and
+        the inputs keep their requires_grad flags whether or not the caller runs under torch.no_grad(), so the flags
+        of a leaf say nothing: RadFoamScene hands its nn.Parameter points to every render, evaluation included.  What
+        does tell is a COMPUTED input: the scene's attributes are cat(...softplus(density)...), which require grad
+        exactly when the graph is being recorded.  So: attributes.requires_grad, or -- for callers outside a Function,
+        where grad mode is the caller's -- points.requires_grad with grad mode on.  A wrong "no" only costs speed
+        (trace_backward re-walks instead of replaying), never correctness."""
         if self.record_trail == "auto":
-            return bool(points.requires_grad or attributes.requires_grad)
+            return bool(attributes.requires_grad or (points.requires_grad and torch.is_grad_enabled()))
         return bool(self.record_trail)
 
     # -- introspection (Pipeline::attribute_dim / attribute_type, pipeline.cu:768-774) ----------

@@ -7,6 +7,11 @@ face tables); what its callers consume is ``permutation()``, ``point_adjacency()
 ``rf_kd_order`` -> ``rf_build_aabb_tree`` -> ``rf_delaunay_adjacency`` (radfoam_amd/csrc/rf_delaunay.hip,
 rf_star.hpp): every point builds its own Delaunay star with exact predicates, certified against the tree.
 
+Limits (rf_star.hpp): at most 4095 Delaunay neighbours per point and 64 points with more than 249 (beyond that a
+RuntimeError, not the retryable TriangulationFailedError); the exact predicates snap coordinates more than 2^38 times
+finer than the coarsest coordinate of the same predicate to its grid -- inputs like that are reported as an ambiguous
+triangulation (unmatched edges), not triangulated wrongly.
+
 No CPU path in this module: it needs the HIP library and CUDA (HIP) tensors.  The tetrahedra themselves
 (``tets()``, ``tet_adjacency()``, ``vert_to_tet()`` -- only the reference's viewer reads them) are not produced
 on the GPU; those three getters triangulate once more with Qhull on the host when asked.
@@ -123,6 +128,14 @@ def delaunay_adjacency(points: torch.Tensor, tree: torch.Tensor | None = None, s
                  hull_candidates=int(info[11]))
     if stats["duplicate_points"]:
         raise TriangulationFailedError("duplicate points found")
+    if stats["oversized_stars"]:
+        # Not a TriangulationFailedError: perturbing the points (what RadFoamScene.update_triangulation does about
+        # that one, scene.py:160-186) cannot shrink a hub, so a retry loop would only end in "aborted triangulation
+        # after 25 attempts".  The reference's global mesh has no per-vertex bound; this implementation does.
+        raise RuntimeError(
+            "Delaunay triangulation: %d point(s) have more than 4095 Delaunay neighbours or more than 64 points have "
+            "more than 249 (a point inside a large empty shell of points); this build keeps at most 4095 neighbours "
+            "per point and 64 such hubs per triangulation -- remove or move those points" % stats["oversized_stars"])
     if stats["failed_stars"] or stats["asymmetric_edges"]:
         raise TriangulationFailedError(
             "ambiguous triangulation (%d stars failed: %d without a non-coplanar start, %d inconsistent, %d with more "

@@ -38,8 +38,12 @@ static int one_star(const float *pts, uint32_t n, const Tree &tr, const HullSet 
     int ns = 0;
     if (old_adj) {
         for (uint32_t e = old_off[i]; e < old_off[i + 1] && ns < V - 1; ++e) seeds[ns++] = old_adj[e];
-    } else {
-        const uint32_t b0 = i & ~63u, b1 = b0 + 64 < n ? b0 + 64 : n;
+        if (ns < 3) ns = 0;   // nothing usable in the previous list: the block's points, as gather_seeds does
+    }
+    if (ns == 0) {
+        uint32_t b0, bc;
+        seed_window(n, i, b0, bc);
+        const uint32_t b1 = b0 + bc;
         float d2[64];
         for (uint32_t k = b0; k < b1; ++k) {
             const float dx = pts[3 * k] - pts[3 * i], dy = pts[3 * k + 1] - pts[3 * i + 1], dz = pts[3 * k + 2] - pts[3 * i + 2];
@@ -149,7 +153,9 @@ int star_host_delaunay_owner(const float *pts, uint32_t n, const float *tree, ui
             nodes_knn += vis;
             vis = 0;
         } else {
-            const uint32_t b0 = i & ~63u, b1 = b0 + 64 < n ? b0 + 64 : n;
+            uint32_t b0, bc;
+        seed_window(n, i, b0, bc);
+        const uint32_t b1 = b0 + bc;
             float d2[64];
             for (uint32_t k = b0; k < b1; ++k) {
                 const float dx = pts[3 * k] - pts[3 * i], dy = pts[3 * k + 1] - pts[3 * i + 1], dz = pts[3 * k + 2] - pts[3 * i + 2];

@@ -89,6 +89,24 @@ def test_host_stars_equal_qhull(name):
     assert np.array_equal(off, off0) and np.array_equal(adj, adj0)
 
 
+@pytest.mark.parametrize("n", [33, 63, 65, 641, 642, 643, 1025, 2050])
+def test_host_short_last_block_is_seeded_from_the_last_64_points(n):
+    """with n % 64 in 1..3 the last kd-block has fewer than three other points, the first-pass
+    seeds of its stars could not span a tetrahedron and the build failed as 'ambiguous triangulation' whatever the
+    perturbation (4.7 % of all point counts).  The seed window of a short last block is the last 64 points now."""
+    rng = np.random.default_rng(100 + n)
+    pts = _kd(rng.uniform(-1, 1, size=(n, 3)))
+    off0, adj0 = foam.delaunay_csr(pts)
+    off, adj, info = S.delaunay(pts)
+    assert info["bad"] == 0 and (info["status"] == 0).all()
+    assert np.array_equal(off, off0) and np.array_equal(adj, adj0)
+    # the incremental path with nothing usable in the seed lists falls back to the same window
+    empty = (np.zeros(n + 1, dtype=np.uint32), np.zeros(0, dtype=np.uint32))
+    off, adj, info = S.delaunay(pts, old=empty)
+    assert info["bad"] == 0
+    assert np.array_equal(off, off0) and np.array_equal(adj, adj0)
+
+
 def _hub_cloud(rng):
     """A point at the centre of an empty shell of 3000 points (a floater inside a densely sampled surface): more
     than 2000 Delaunay neighbours."""
@@ -270,6 +288,32 @@ def test_gpu_stars_equal_qhull(name):
     assert stats["asymmetric_edges"] == 0 and stats["failed_stars"] == 0
     if name == "sheet":
         assert stats["large_stars"] > 0   # the large instance was exercised
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [65, 641, 642, 643, 1025, 100003])
+def test_gpu_short_last_block(n):
+    """n % 64 in 1..3: from scratch, incrementally with the previous lists, and incrementally with
+    empty seed lists, through radfoam.Triangulation as the reference's scene drives it."""
+    import torch
+    import radfoam
+    from radfoam_amd import triangulation
+    rng = np.random.default_rng(200 + n)
+    pts = _kd(rng.uniform(-1, 1, size=(n, 3)))
+    off0, adj0 = foam.delaunay_csr(pts)
+    adj, off, stats = triangulation.delaunay_adjacency(_t(pts))
+    assert stats["failed_stars"] == 0 and stats["asymmetric_edges"] == 0
+    assert np.array_equal(off.cpu().numpy(), off0) and np.array_equal(adj.cpu().numpy(), adj0)
+    empty = (torch.zeros(0, dtype=torch.int32, device="cuda").view(torch.uint32),
+             torch.zeros(n + 1, dtype=torch.int32, device="cuda").view(torch.uint32))
+    adj, off, stats = triangulation.delaunay_adjacency(_t(pts), seed=empty)
+    assert np.array_equal(off.cpu().numpy(), off0) and np.array_equal(adj.cpu().numpy(), adj0)
+    tri = radfoam.Triangulation(_t(pts))
+    moved = (pts + rng.normal(0, 1e-4, size=pts.shape)).astype(np.float32)
+    assert tri.rebuild(_t(moved), incremental=True) is False
+    off1, adj1 = foam.delaunay_csr(moved)
+    assert np.array_equal(tri.point_adjacency().cpu().numpy(), adj1)
+    assert np.array_equal(tri.point_adjacency_offsets().cpu().numpy(), off1)
 
 
 @pytest.mark.gpu
