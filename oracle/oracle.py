@@ -176,6 +176,26 @@ def trace_forward(sh_degree, points, attributes, adjacency, offsets, rays, start
     return out
 
 
+def trace_paths(sh_degree, points, attributes, adjacency, offsets, rays, start_point, cap=256,
+                weight_threshold=None, max_intersections=None, num_threads=0):
+    """(cells uint32[R, cap], t1 float32[R, cap], n uint32[R]): the cells every ray scans and where it leaves them
+    (fp32 attributes only).  For scheduling studies of the kernels (scripts/model_*.py), not a parity output."""
+    points, attributes = _c(points, np.float32), _c(attributes, np.float32)
+    adjacency, offsets = _c(adjacency, np.uint32), _c(offsets, np.uint32)
+    rays = _c(rays, np.float32).reshape(-1, 6)
+    r = rays.shape[0]
+    start = _c(np.broadcast_to(start_point, (r,)), np.uint32)
+    diff = build_adjacent_diff(points, adjacency, offsets, pad=1)
+    cells = np.full((r, cap), NONE, dtype=np.uint32)
+    t1 = np.full((r, cap), np.inf, dtype=np.float32)
+    n = np.zeros(r, dtype=np.uint32)
+    lib().rfo_trace_paths(C.c_int(sh_degree), _settings(weight_threshold, max_intersections),
+                          C.c_uint32(points.shape[0]), _p(points), _p(attributes), C.c_uint32(adjacency.shape[0]),
+                          _p(adjacency), _p(offsets), _p(diff), C.c_uint32(r), _p(rays), _p(start), C.c_uint32(cap),
+                          _p(cells), _p(t1), _p(n), C.c_int(num_threads))
+    return cells, t1, n
+
+
 def trace_backward(sh_degree, points, attributes, adjacency, offsets, rays, start_point,
                    rgb_out, grad_in, depth_quantiles=None, depth_indices=None, depth_grad_in=None,
                    ray_error=None, weight_threshold=None, max_intersections=None, diff=None,

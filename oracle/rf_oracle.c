@@ -71,6 +71,11 @@ static int rfo_scan_mode = 0;
 void rfo_set_scan_mode(int mode) { rfo_scan_mode = mode == 1 ? 1 : 0; }
 int rfo_get_scan_mode(void) { return rfo_scan_mode; }
 
+/* rfo_trace_paths: per-thread recorder of a ray's walk (scheduling studies of the kernels: scripts/model_*.py) */
+static _Thread_local uint32_t *rfo_path_cells = NULL;
+static _Thread_local float *rfo_path_t1 = NULL;
+static _Thread_local uint32_t rfo_path_cap = 0;
+
 /* ------------------------------------------------------------------------------------ */
 /* half <-> float, software, RNE (== __float2half / __half2float)                        */
 
@@ -354,6 +359,30 @@ void rfo_trace_forward(int sh_degree, int attr_half, rfo_settings settings, uint
  * ray_grad is not an argument: the reference allocates but never writes it.
  * strict: see backward_ray.
  */
+/* The cells every ray scans (cells[r][k], k < min(n_r, cap)) and the parameter at which it leaves each (t1[r][k], +inf
+ * when the walk ends there); returns nothing else: a scheduling study tool, not part of the parity surface. */
+void rfo_trace_paths(int sh_degree, rfo_settings settings, uint32_t num_points, const float *points,
+                     const float *attributes, uint32_t adj_size, const uint32_t *adj, const uint32_t *offsets,
+                     const uint16_t *diff, uint32_t num_rays, const float *rays, const uint32_t *start, uint32_t cap,
+                     uint32_t *cells, float *t1, uint32_t *num_intersections, int num_threads) {
+    int A = 1 + 3 * (sh_degree + 1) * (sh_degree + 1);
+    (void)adj_size;
+    foam_t_f32 fm = {sh_degree, A, settings, num_points, points, attributes, adj, offsets, diff};
+    int nt = pick_threads(num_threads);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+    for (int64_t r = 0; r < (int64_t)num_rays; ++r) {
+        float rgba[4];
+        rfo_path_cells = cells + (size_t)r * cap;
+        rfo_path_t1 = t1 + (size_t)r * cap;
+        rfo_path_cap = cap;
+        num_intersections[r] = forward_ray_f32(&fm, rays + 6 * (size_t)r, start[r], 0, NULL, rgba, NULL, NULL, NULL, 1,
+                                               NULL, 0);
+        rfo_path_cells = NULL;
+        rfo_path_t1 = NULL;
+        rfo_path_cap = 0;
+    }
+}
+
 void rfo_trace_backward(int sh_degree, int attr_half, rfo_settings settings, uint32_t num_points,
                         const float *points, const void *attributes, uint32_t adj_size,
                         const uint32_t *adj, const uint32_t *offsets, const uint16_t *diff,

@@ -39,6 +39,19 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources and headers, in a fixed order: what a set of hardware counters was measured on
+    (profiles/counters.json records it; bench.py refuses to quote counters of another build)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(SOURCES + HEADERS):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
     return _stale(OUTPUT, SOURCES + HEADERS)
 
@@ -66,4 +79,9 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_hip(force=True, verbose=True))
+    import sys
+
+    if "--source-hash" in sys.argv:
+        print(source_hash())
+    else:
+        print(build_hip(force=True, verbose=True))

@@ -196,104 +196,6 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(
     degree[i] = (uint32_t)deg;
 }
 
-// ---- EXPERIMENTAL: every tetrahedron certified once (RF_DELAUNAY_OWNER=1|2; rf_star.hpp) ---------------
-// Host-validated (tests/test_delaunay.py runs the same header functions through tests/host_harness), not yet measured
-// on the GPU: the default build does not use these kernels.  Pass 1 = the first pass with only the owned triangles
-// certified, the star saved as a 760-byte record; pass 2 reloads it and closes the rest from the owners' records or
-// the tree.  Stars parked in either pass go through the second / third pass of the default build.
-
-using SmallRecord = star::StarRecord<kSmallV, kSmallT>;
-
-struct RecordLookup {
-    const SmallRecord *records;
-    __device__ bool operator()(uint32_t owner, uint32_t g0, uint32_t g1, uint32_t g2) const {
-        return star::record_certifies(records[owner], kSmallV, g0, g1, g2);
-    }
-};
-
-// what both passes do with a finished (or unfinished) first-instance star
-__device__ __forceinline__ void retire_small_star(const SmallStar &s, uint32_t i, uint32_t *__restrict__ rows,
-                                                  uint32_t *__restrict__ degree, uint32_t *__restrict__ overflow_list,
-                                                  uint32_t *__restrict__ hull_list, StarCounters *__restrict__ counters,
-                                                  bool final_pass) {
-    uint32_t *row = rows + (size_t)i * kSmallV;
-    if (s.status == star::kOverflow || s.status == star::kPending) {
-        overflow_list[atomicAdd(&counters->overflow, 1u)] = i;
-        hull_list[atomicAdd(&counters->hull, 1u)] = i;
-        uint32_t c = 0;
-        for (int k = 1; k < kSmallV; ++k)
-            if (s.v[k].use) row[c++] = s.v[k].g;
-        degree[i] = c;
-    } else if (s.status != star::kOk) {
-        atomicAdd(&counters->failed[s.status], 1u);
-        degree[i] = 0;
-    } else if (final_pass) {
-        bool hull;
-        const int deg = star::star_neighbours(s, row, 1, &hull);
-        if (hull) hull_list[atomicAdd(&counters->hull, 1u)] = i;
-        degree[i] = (uint32_t)deg;
-    }
-}
-
-template <int WAVES_PER_SIMD, bool TREE_KNN>
-__global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_owner_pass1_kernel(
-    const float *__restrict__ pts, uint32_t n, const float *__restrict__ tree, uint32_t depth,
-    const uint32_t *__restrict__ seed_adj, const uint32_t *__restrict__ seed_off, SmallRecord *__restrict__ records,
-    uint32_t *__restrict__ rows, uint32_t *__restrict__ degree, uint32_t *__restrict__ overflow_list,
-    uint32_t *__restrict__ hull_list, uint32_t budget, StarCounters *__restrict__ counters) {
-    __shared__ float block_pts[64 * 3];
-    // candidates of a lane without a previous list: the block's own points (a short last block: the last 64 points)
-    uint32_t block_first, block_count;
-    star::seed_window(n, blockIdx.x * 64u, block_first, block_count);
-    for (uint32_t k = threadIdx.x; k < 3 * block_count; k += 64) block_pts[k] = pts[3 * (size_t)block_first + k];
-    __syncthreads();
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= n) return;
-    SmallStar s;
-    star::star_reset(s, i, pts + 3 * (size_t)i);
-    const star::Tree tr{tree, n, depth};
-    const star::HullSet pass{nullptr, 0u, budget};
-    uint32_t seeds[kSmallV];
-    uint32_t visited = 0, inserted = 0;
-    int ns;
-    if (TREE_KNN && !seed_adj) ns = star::star_knn<24>(tr, pts, i, seeds, visited);
-    else ns = gather_seeds<kSmallV, kSmallT>(pts, n, i, seed_adj, seed_off, block_pts, block_first, block_count, seeds,
-                                             kSmallV - 1);
-    star::star_certify_owned(s, tr, pts, pass, seeds, ns, visited, inserted);
-    star::star_save(s, records[i]);
-    atomicAdd(&counters->inserted, inserted);
-    const uint32_t old = atomicAdd(&counters->nodes_lo, visited);
-    if (old + visited < old) atomicAdd(&counters->nodes_hi, 1u);
-    retire_small_star(s, i, rows, degree, overflow_list, hull_list, counters, false);
-}
-
-template <int WAVES_PER_SIMD>
-__global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_owner_pass2_kernel(
-    const float *__restrict__ pts, uint32_t n, const float *__restrict__ tree, uint32_t depth,
-    const SmallRecord *__restrict__ records, uint32_t *__restrict__ rows, uint32_t *__restrict__ degree,
-    uint32_t *__restrict__ overflow_list, uint32_t *__restrict__ hull_list, uint32_t budget,
-    StarCounters *__restrict__ counters) {
-    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-    if (i >= n || records[i].status != star::kOk) return;   // unfinished in pass 1: already on the lists
-    SmallStar s;
-    star::star_load(s, records[i], i, pts);
-    const star::Tree tr{tree, n, depth};
-    const star::HullSet pass{nullptr, 0u, budget};
-    uint32_t visited = 0, inserted = 0, closed = 0;
-    star::star_close(s, tr, pts, pass, RecordLookup{records}, visited, inserted, closed);
-    atomicAdd(&counters->inserted, inserted);
-    const uint32_t old = atomicAdd(&counters->nodes_lo, visited);
-    if (old + visited < old) atomicAdd(&counters->nodes_hi, 1u);
-    retire_small_star(s, i, rows, degree, overflow_list, hull_list, counters, true);
-}
-
-// ---- second pass: one WAVE per star --------------------------------------------------------------------------------
-// Stars the first pass parked (a query ran out of budget: rim of the cloud, rf_star.hpp HullSet) or could not hold.
-// The star (large instance, 14 KB) sits in LDS, thread 0 does the link surgery, the block's waves each take one of
-// the star's open queries, and a query is answered by its whole wave: the tree is walked six levels at a time -- the 64 descendants of a node are consecutive in memory, one
-// box per lane, a ballot keeps those the region touches (the reference's warp_traverse walks its tree the same way,
-// 32 wide: src/aabb_tree/aabb_tree.cuh:77-152) -- and a ghost query is one pass over the hull candidates, 64 at a time.
-
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
@@ -736,7 +638,7 @@ static KdLayout kd_layout(uint32_t n) {
 }
 
 struct DelaunayLayout {
-    size_t rows, degree, overflow, hull, counters, big_rows, huge_list, huge_rows, huge_arena, scan_temp, records, scan_bytes, total;
+    size_t rows, degree, overflow, hull, counters, big_rows, huge_list, huge_rows, huge_arena, scan_temp, scan_bytes, total;
     uint32_t second_rows;   // stars the second pass has result rows for
 };
 
@@ -748,11 +650,6 @@ static size_t scan_temp_bytes(uint32_t n) {
 }
 
 static uint32_t default_second_rows(uint32_t n) { return n / 32 < 1024 ? 1024 : n / 32; }
-
-static int owner_mode() {   // 0 = default build; 1 / 2 = the experimental two-pass build (kd-block seeds / tree k-NN seeds)
-    const char *e = getenv("RF_DELAUNAY_OWNER");
-    return e ? atoi(e) : 0;
-}
 
 static DelaunayLayout delaunay_layout(uint32_t n, uint32_t second_rows, size_t scan_bytes) {
     DelaunayLayout L{};
@@ -774,7 +671,6 @@ static DelaunayLayout delaunay_layout(uint32_t n, uint32_t second_rows, size_t s
     L.huge_rows = take((size_t)kHugeStars * kHugeV * 4);
     L.huge_arena = take((size_t)kHugeStars * sizeof(HugeStar));
     L.scan_temp = take(scan_bytes);
-    L.records = owner_mode() ? take((size_t)n * sizeof(SmallRecord)) : 0;
     L.total = at;
     return L;
 }
@@ -905,20 +801,7 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
 #define RF_LAUNCH_STARS(W)                                                                                        \
     hipLaunchKernelGGL(delaunay_star_kernel<W>, dim3(blocks), dim3(64), 0, s, points, num_points, aabb_tree, depth, \
                        seed_adjacency, seed_offsets, rows, degree, overflow, hull, ghost_budget, counters)
-    const int owner = owner_mode();
-    if (owner) {
-        SmallRecord *records = reinterpret_cast<SmallRecord *>(base + L.records);
-        if (owner >= 2)
-            hipLaunchKernelGGL((delaunay_owner_pass1_kernel<6, true>), dim3(blocks), dim3(64), 0, s, points, num_points,
-                               aabb_tree, depth, seed_adjacency, seed_offsets, records, rows, degree, overflow, hull,
-                               ghost_budget, counters);
-        else
-            hipLaunchKernelGGL((delaunay_owner_pass1_kernel<6, false>), dim3(blocks), dim3(64), 0, s, points, num_points,
-                               aabb_tree, depth, seed_adjacency, seed_offsets, records, rows, degree, overflow, hull,
-                               ghost_budget, counters);
-        hipLaunchKernelGGL(delaunay_owner_pass2_kernel<6>, dim3(blocks), dim3(64), 0, s, points, num_points, aabb_tree,
-                           depth, records, rows, degree, overflow, hull, ghost_budget, counters);
-    } else if (waves <= 4) RF_LAUNCH_STARS(4);
+    if (waves <= 4) RF_LAUNCH_STARS(4);
     else RF_LAUNCH_STARS(6);
 #undef RF_LAUNCH_STARS
     StarCounters host{};

@@ -86,6 +86,7 @@ struct FwdParams {
     rf_camera cam;
     float inv_tan_half_fov;
     uint32_t *rgba8;
+    float sync_delta;       // SYNC instances: a lane steps only while t0 <= (wave's smallest live t0) + sync_delta
 };
 
 struct BwdParams {
@@ -109,6 +110,7 @@ struct BwdParams {
     uint32_t trail_cap, trail_slots;
     unsigned long long *stats;   // optional scatter counters (experiments): [0] row flushes [1] values flushed
                                  // [2] lane contributions that bypassed the block cache [3] cached lane contributions
+    float sync_delta;            // trail replay: as FwdParams::sync_delta (0 = off)
 };
 
 constexpr int kBlock = 256;
@@ -493,7 +495,11 @@ constexpr int forward_waves(int deg, bool quant, bool stats) {
     return deg <= 2 ? RF_FWD_WAVES_MAIN : RF_FWD_WAVES_D3;
 }
 
-template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS>
+// SYNC (flat batches, rf_launch_opts::sync_delta > 0): the lanes of a wave are kept in one depth slab -- a lane steps
+// only while its t0 is within sync_delta of the wave's laggard -- so that rays of a sparse batch, which de-synchronise
+// in depth and then stream past each other through the same cells many steps apart (every visit an L2 miss), meet
+// their cells together.  Pure scheduling: the per-ray arithmetic, and therefore every output bit, is unchanged.
+template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS, bool SYNC = false>
 __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forward_kernel(FwdParams p) {
     const uint32_t lane = threadIdx.x & 63u;
 #ifdef RF_EXPERIMENT_TIMELINE
@@ -570,14 +576,19 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
 #endif
     while (ballot(alive) != 0ull) {
         wave_steps++;
-        if (alive) {
+        bool go = alive;   // lanes that take a step now
+        if constexpr (SYNC) {
+            const float tmin = wave_min(alive ? t0 : __builtin_inff());
+            go = alive && t0 <= tmin + p.sync_delta;
+        }
+        if (go) {
             n++;
-            if (n > max_steps) alive = false;
+            if (n > max_steps) alive = go = false;
         }
         ScanResult sr;
         sr.t1 = __builtin_inff();
         sr.k = kNone;
-        if (alive) {
+        if (go) {
 #if RF_SCAN_PIPE >= 2
             sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, &gA, &gB);
 #else
@@ -588,11 +599,11 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
                 st_faces += fv.offsets[cur + 1] - fv.offsets[cur];
                 if (p.visit_marks) p.visit_marks[cur] = (uint8_t)1;
             }
-            if (sr.k == kNone) alive = false;
+            if (sr.k == kNone) alive = go = false;
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (alive) {
+        if (go) {
             const Link link = fv.link[nb + sr.k];
             nxt = link.nbr;
             nnb = link.first;
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
                 }
             }
         }
-        if (alive) {
+        if (go) {
             const float t1 = sr.t1;
             if (want_stats) st_hops++;
             if (want_stats && t1 > t0) {
@@ -1396,17 +1407,25 @@ struct TrailWalker {
         n = 0;
     }
 
-    // one hop of every live lane; G receives the gradients of the segment just crossed (if any)
+    // one hop of every live lane (with sync_delta > 0: of the live lanes within sync_delta of the wave's laggard, see
+    // forward_kernel's SYNC); G receives the gradients of the segment just crossed (if any)
     __device__ __forceinline__ void step(const BwdParams &p, StepGrad &G) {
         const FoamView &fv = p.foam;
-        if (alive) {
-            n++;
-            if (n > p.settings.max_intersections) alive = false;
+        bool go = alive;
+        if (p.sync_delta > 0.0f) {
+            const float tmin = wave_min(alive ? R.t0 : __builtin_inff());
+            go = alive && R.t0 <= tmin + p.sync_delta;
         }
-        if (alive && i >= hops) alive = false;   // forward stopped here (no exit face / step cap / opaque)
-        float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        uint32_t id2 = 0;
-        if (alive) {
+        if (go) {
+            n++;
+            if (n > p.settings.max_intersections) alive = go = false;
+        }
+        if (go && i >= hops) alive = go = false;   // forward stopped here (no exit face / step cap / opaque)
+        float4 q1 = q0;
+        uint32_t id2 = id1;
+        if (go) {
+            q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            id2 = 0;
             if (i + 1 < recorded) q1 = fv.cells[id1];
             if (i + 2 < recorded) id2 = p.trail[(size_t)(i + 2) * slots + slot];
         }
@@ -1414,13 +1433,13 @@ struct TrailWalker {
         // cell records exactly as rf_prepare_foam rounds it
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float t1 = 0.0f;
-        if (alive) {
+        if (go) {
             nhead = q0;
             float ox, oy, oz, dp;
             face_offset(head, nhead, ox, oy, oz);
             face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
         }
-        if (alive) {
+        if (go) {
             if (t1 > R.t0) {
                 if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
             }
@@ -1428,10 +1447,11 @@ struct TrailWalker {
             cur = id0;
             head = nhead;
             i++;
+            // the pipeline registers rotate only for lanes that stepped (a waiting lane keeps id0 / id1 / q0)
+            id0 = id1;
+            id1 = id2;
+            q0 = q1;
         }
-        id0 = id1;
-        id1 = id2;
-        q0 = q1;
     }
 };
 
@@ -2028,12 +2048,19 @@ struct LaunchForward {
     static int run(const FwdParams &p, bool bench, hipStream_t stream) {
         uint32_t nb = launch_blocks(p.grid);
         if (nb == 0) return RF_OK;
+        const bool sync = p.sync_delta > 0.0f;
         if (bench)
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+        else if (p.stats && sync)
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, true, true>), dim3(nb), dim3(kBlock), 0, stream, p);
         else if (p.stats)
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, true>), dim3(nb), dim3(kBlock), 0, stream, p);
+        else if (p.nq && sync)
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, true>), dim3(nb), dim3(kBlock), 0, stream, p);
         else if (p.nq)
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+        else if (sync)
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, true>), dim3(nb), dim3(kBlock), 0, stream, p);
         else
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
         return check_launch(bench ? "rf_trace_benchmark" : "rf_trace_forward");
@@ -2198,6 +2225,9 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     p.contribution = static_cast<float *>(point_contribution);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
     p.visit_marks = opts->stats ? opts->visit_marks : nullptr;
+    // depth synchronisation: flat batches only (the lanes of an image tile stay together by themselves)
+    p.sync_delta = (p.grid.img_w == 0u && opts->sync_delta > 0.0f && opts->sync_delta == opts->sync_delta)
+                       ? opts->sync_delta : 0.0f;
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: trail_slots smaller than rf_trail_slots()");
@@ -2260,6 +2290,8 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     p.attr_grad = static_cast<float *>(attribute_grad);
     p.point_error = static_cast<float *>(point_error);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
+    p.sync_delta = (p.grid.img_w == 0u && opts->sync_delta > 0.0f && opts->sync_delta == opts->sync_delta)
+                       ? opts->sync_delta : 0.0f;
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: trail_slots smaller than rf_trail_slots()");

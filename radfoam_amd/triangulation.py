@@ -102,6 +102,8 @@ def delaunay_adjacency(points: torch.Tensor, tree: torch.Tensor | None = None, s
         seed_adj, seed_off = seed[0].contiguous(), seed[1].contiguous()
         if seed_off.numel() != n + 1 or seed_adj.dtype != torch.uint32 or seed_off.dtype != torch.uint32:
             raise RuntimeError("seed lists must be uint32 tensors of a triangulation of the same number of points")
+        if seed_adj.numel() == 0:   # nothing to seed from (an empty tensor has no address to hand over): from scratch
+            seed_adj = seed_off = None
     ws = torch.empty(max(int(lib.rf_delaunay_workspace_bytes(n)), 256), dtype=torch.uint8, device=dev)
     capacity = 20 * n   # the reference gives up beyond 20 tetrahedra per point (delaunay.cu:352); E ~ 15.5 N
     info = (C.c_uint32 * 12)()

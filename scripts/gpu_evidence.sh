@@ -31,6 +31,7 @@ if has prof; then
   done
 fi
 if has pmc; then
+  python $R/radfoam_amd/build.py --source-hash > $O/csrc_sha256.txt   # the build these counters describe
   rocprofv3 -L > $O/counters_list.txt 2>&1
   for w in $PMCW; do
     BENCH="python $R/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline"

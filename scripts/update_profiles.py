@@ -45,9 +45,16 @@ for f in ("pytest_gpu.log", "smoke.log"):
 # profiles/counters.json: workload -> {source, kernels: {kernel: counters}}, merged over rounds / tags
 cj = os.path.join(ROOT, "profiles", "counters.json")
 allc = json.load(open(cj)) if os.path.exists(cj) else {}
+sha_file = os.path.join(ev, "csrc_sha256.txt")
+csrc_sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
 for f in sorted(glob.glob(os.path.join(ev, "counters_*.json"))):
     w = os.path.basename(f)[9:-5]
+    if w == "list":
+        continue
     allc[w] = {
+        # sha256 of the kernel sources the passes were taken on (radfoam_amd.build.source_hash() on the GPU box):
+        # bench.py quotes these counters only for the same sources
+        "csrc_sha256": csrc_sha,
         "source": f"profiles/{rnd}/{tag}_{w}_counters.json = per-launch averages of profiles/{rnd}/{tag}_{w}_pmc_pass*_counter_collection.csv "
                   "(rocprofv3 --kernel-trace --pmc, one pass per counter group: SQ+GRBM, SQ+GRBM, FETCH_SIZE, WRITE_SIZE; "
                   "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE tallies 128-B requests as 64 B, "

@@ -19,6 +19,7 @@
 #define RF_STAR_NOINLINE static __attribute__((noinline))
 #define RF_STAR_NOUNROLL
 #include "../../../radfoam_amd/csrc/rf_star.hpp"
+#include "star_owner.hpp"
 
 using namespace rf::star;
 using S64 = Star<64, 124>;

@@ -20,6 +20,7 @@ static thread_local std::vector<std::pair<uint32_t, int>> *g_trace = nullptr;
 #define RF_STAR_NOINLINE static __attribute__((noinline))
 #define RF_STAR_NOUNROLL
 #include "../../radfoam_amd/csrc/rf_star.hpp"
+#include "experiments/star_owner.hpp"   // research code: the owner-certified two-pass build (not in the product)
 
 using namespace rf::star;
 
@@ -123,7 +124,7 @@ int star_host_delaunay(const float *pts, uint32_t n, const float *tree, uint32_t
     return bad;
 }
 
-// The experimental two-pass build (rf_star.hpp: star_certify_owned / star_close), as the owner kernels of
+// The experimental two-pass build (experiments/star_owner.hpp: star_certify_owned / star_close), as the owner kernels (removed from the product in round 3) of
 // rf_delaunay.hip run it: pass 1 certifies owned triangles and saves records, pass 2 closes the rest from the owners'
 // records or the tree; stars parked in either pass go to the large instance with the hull candidates, as in the
 // default build.  tree_knn = 0: seeds from the kd-block; 24: the 24 nearest points by a tree walk.

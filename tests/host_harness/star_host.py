@@ -10,7 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libstar_host.so")
-_SRC = [os.path.join(_HERE, "star_host.cpp"), os.path.join(_HERE, "..", "..", "radfoam_amd", "csrc", "rf_star.hpp")]
+_SRC = [os.path.join(_HERE, "star_host.cpp"), os.path.join(_HERE, "..", "..", "radfoam_amd", "csrc", "rf_star.hpp"),
+        os.path.join(_HERE, "experiments", "star_owner.hpp")]
 
 
 def build():

@@ -335,21 +335,6 @@ def test_gpu_hub_and_shell():
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(__import__("os").environ.get("RF_TEST_EXPERIMENTAL") != "1",
-                    reason="the two-pass owner build is host-validated only so far (DESIGN.md 7.4): "
-                           "RF_TEST_EXPERIMENTAL=1 runs it on the GPU")
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_gpu_owner_build_equals_qhull(mode, monkeypatch):
-    from radfoam_amd import triangulation
-    monkeypatch.setenv("RF_DELAUNAY_OWNER", mode)
-    rng = np.random.default_rng(13)
-    pts = _kd(rng.uniform(-1, 1, size=(60000, 3)))
-    off0, adj0 = foam.delaunay_csr(pts)
-    adj, off, stats = triangulation.delaunay_adjacency(_t(pts))
-    assert np.array_equal(off.cpu().numpy(), off0) and np.array_equal(adj.cpu().numpy(), adj0)
-
-
-@pytest.mark.gpu
 def test_gpu_stars_on_the_cached_foams():
     """Whole BASELINE foams: the lists equal the cached Qhull CSR (500 k always; 2 M when its cache is here)."""
     import os
