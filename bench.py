@@ -97,9 +97,6 @@ def parse_args(argv=None):
                     help="depth quantiles per ray (train.py:176-180 draws 2 per ray, sorted descending, and backpropagates "
                          "through the depths); 0 = the headline configuration of SURVEY 8(d)")
     ap.add_argument("--backward-mode", type=int, default=0)
-    ap.add_argument("--sync-cells-bwd", type=float, default=None, help="the same for the backward replay alone")
-    ap.add_argument("--sync-cells", type=float, default=None,
-                    help="flat batches: depth synchronisation of a wave's rays, in mean cell spacings (Pipeline.sync_cells)")
     ap.add_argument("--weak", action="store_true", help="N>1: one frame per rank instead of one frame cut by rows")
     ap.add_argument("--exchange", choices=["sparse", "dense"], default="sparse")
     ap.add_argument("--no-rebalance", action="store_true", help="N>1: keep the even row split")
@@ -304,10 +301,6 @@ def main():
         import radfoam
         pipe = radfoam.create_pipeline(sh_degree, attr_dtype)
         pipe.backward_mode = args.backward_mode
-        if args.sync_cells is not None:
-            pipe.sync_cells = args.sync_cells
-        if args.sync_cells_bwd is not None:
-            pipe.sync_cells_backward = args.sync_cells_bwd
         pipe.record_trail = not W["forward_only"]   # trace_backward is driven by hand on plain tensors
     else:
         mod, fn = test_factory.split(":")
@@ -560,8 +553,6 @@ def main():
             "weight_threshold": 0.05 if W["kind"] == "render" else 1e-3, "max_intersections": 1024,
             "parallelism": par,
             "backward_mode": args.backward_mode,
-            "sync_cells": getattr(pipe, "sync_cells", 0.0),
-            "sync_cells_backward": getattr(pipe, "sync_cells_backward", None),
         },
         "detail": detail,
     }

@@ -90,13 +90,6 @@ typedef struct rf_launch_opts {
     /* any ray scans cell i (the caller zeroes it).  Feeds the compulsory-traffic floor of bench.py's   */
     /* roofline: bytes of the distinct cells, face lists and colour rows a frame touches at least once. */
     uint8_t *visit_marks;
-    /* Depth synchronisation of a wave's rays (flat batches; 0 = off).  A lane steps only while its ray parameter    */
-    /* t0 is within sync_delta of the smallest t0 among the wave's live lanes, so that the rays of a wave stay in     */
-    /* the same slab of the foam: they then meet the same cells within a few steps of each other and share their    */
-    /* fetches (forward) / their rows in the block's gradient cache (backward) instead of streaming past each other.  */
-    /* Scheduling only: every result is the same as with 0 (sums in another order).  In units of the ray parameter:   */
-    /* a few mean cell spacings (the Python binding derives it from the points' bounding box).                        */
-    float sync_delta;
 } rf_launch_opts;
 
 /* Last error message of the calling thread ("" if none). */

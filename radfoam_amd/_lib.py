@@ -57,7 +57,6 @@ class LaunchOpts(C.Structure):
         ("trail_slots", C.c_uint32),
         ("ray_order", C.c_void_p),
         ("visit_marks", C.c_void_p),
-        ("sync_delta", C.c_float),
     ]
 
 

@@ -86,7 +86,6 @@ struct FwdParams {
     rf_camera cam;
     float inv_tan_half_fov;
     uint32_t *rgba8;
-    float sync_delta;       // SYNC instances: a lane steps only while t0 <= (wave's smallest live t0) + sync_delta
 };
 
 struct BwdParams {
@@ -110,7 +109,6 @@ struct BwdParams {
     uint32_t trail_cap, trail_slots;
     unsigned long long *stats;   // optional scatter counters (experiments): [0] row flushes [1] values flushed
                                  // [2] lane contributions that bypassed the block cache [3] cached lane contributions
-    float sync_delta;            // trail replay: as FwdParams::sync_delta (0 = off)
 };
 
 constexpr int kBlock = 256;
@@ -495,11 +493,7 @@ constexpr int forward_waves(int deg, bool quant, bool stats) {
     return deg <= 2 ? RF_FWD_WAVES_MAIN : RF_FWD_WAVES_D3;
 }
 
-// SYNC (flat batches, rf_launch_opts::sync_delta > 0): the lanes of a wave are kept in one depth slab -- a lane steps
-// only while its t0 is within sync_delta of the wave's laggard -- so that rays of a sparse batch, which de-synchronise
-// in depth and then stream past each other through the same cells many steps apart (every visit an L2 miss), meet
-// their cells together.  Pure scheduling: the per-ray arithmetic, and therefore every output bit, is unchanged.
-template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS, bool SYNC = false>
+template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS>
 __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forward_kernel(FwdParams p) {
     const uint32_t lane = threadIdx.x & 63u;
 #ifdef RF_EXPERIMENT_TIMELINE
@@ -576,19 +570,14 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
 #endif
     while (ballot(alive) != 0ull) {
         wave_steps++;
-        bool go = alive;   // lanes that take a step now
-        if constexpr (SYNC) {
-            const float tmin = wave_min(alive ? t0 : __builtin_inff());
-            go = alive && t0 <= tmin + p.sync_delta;
-        }
-        if (go) {
+        if (alive) {
             n++;
-            if (n > max_steps) alive = go = false;
+            if (n > max_steps) alive = false;
         }
         ScanResult sr;
         sr.t1 = __builtin_inff();
         sr.k = kNone;
-        if (go) {
+        if (alive) {
 #if RF_SCAN_PIPE >= 2
             sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz, &gA, &gB);
 #else
@@ -599,11 +588,11 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
                 st_faces += fv.offsets[cur + 1] - fv.offsets[cur];
                 if (p.visit_marks) p.visit_marks[cur] = (uint8_t)1;
             }
-            if (sr.k == kNone) alive = go = false;
+            if (sr.k == kNone) alive = false;
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (go) {
+        if (alive) {
             const Link link = fv.link[nb + sr.k];
             nxt = link.nbr;
             nnb = link.first;
@@ -622,7 +611,7 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
                 }
             }
         }
-        if (go) {
+        if (alive) {
             const float t1 = sr.t1;
             if (want_stats) st_hops++;
             if (want_stats && t1 > t0) {
@@ -1267,7 +1256,10 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 #define RF_BWD_WAVES_D3 3
 #endif
 #ifndef RF_DTABLE_ROWS
-#define RF_DTABLE_ROWS 768
+#define RF_DTABLE_ROWS 640
+#endif
+#ifndef RF_DIRECT_MERGE_ROWS
+#define RF_DIRECT_MERGE_ROWS 0
 #endif
 #ifndef RF_DTABLE_EPOCH
 #define RF_DTABLE_EPOCH 4
@@ -1407,25 +1399,17 @@ struct TrailWalker {
         n = 0;
     }
 
-    // one hop of every live lane (with sync_delta > 0: of the live lanes within sync_delta of the wave's laggard, see
-    // forward_kernel's SYNC); G receives the gradients of the segment just crossed (if any)
+    // one hop of every live lane; G receives the gradients of the segment just crossed (if any)
     __device__ __forceinline__ void step(const BwdParams &p, StepGrad &G) {
         const FoamView &fv = p.foam;
-        bool go = alive;
-        if (p.sync_delta > 0.0f) {
-            const float tmin = wave_min(alive ? R.t0 : __builtin_inff());
-            go = alive && R.t0 <= tmin + p.sync_delta;
-        }
-        if (go) {
+        if (alive) {
             n++;
-            if (n > p.settings.max_intersections) alive = go = false;
+            if (n > p.settings.max_intersections) alive = false;
         }
-        if (go && i >= hops) alive = go = false;   // forward stopped here (no exit face / step cap / opaque)
-        float4 q1 = q0;
-        uint32_t id2 = id1;
-        if (go) {
-            q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            id2 = 0;
+        if (alive && i >= hops) alive = false;   // forward stopped here (no exit face / step cap / opaque)
+        float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t id2 = 0;
+        if (alive) {
             if (i + 1 < recorded) q1 = fv.cells[id1];
             if (i + 2 < recorded) id2 = p.trail[(size_t)(i + 2) * slots + slot];
         }
@@ -1433,13 +1417,13 @@ struct TrailWalker {
         // cell records exactly as rf_prepare_foam rounds it
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float t1 = 0.0f;
-        if (go) {
+        if (alive) {
             nhead = q0;
             float ox, oy, oz, dp;
             face_offset(head, nhead, ox, oy, oz);
             face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
         }
-        if (go) {
+        if (alive) {
             if (t1 > R.t0) {
                 if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
             }
@@ -1447,11 +1431,10 @@ struct TrailWalker {
             cur = id0;
             head = nhead;
             i++;
-            // the pipeline registers rotate only for lanes that stepped (a waiting lane keeps id0 / id1 / q0)
-            id0 = id1;
-            id1 = id2;
-            q0 = q1;
         }
+        id0 = id1;
+        id1 = id2;
+        q0 = q1;
     }
 };
 
@@ -1583,19 +1566,26 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
     // Lanes of a wave staged at a time.  The 48-float rows of SH degree 3 staged for all 64 lanes are 48 KB per
     // block: with the density table two blocks fit a CU (2 waves/SIMD, and every cell gather of a sparse batch
     // is its own cache miss to hide).  Staging one half-wave after the other halves that (4 blocks per CU).
-    constexpr int STAGE_LANES = RF_STAGE_LANES_D3 == 32 && DEG == 3 ? 32 : 64;
+    constexpr int STAGE_LANES = RF_STAGE_LANES_D3 == 32 && DEG >= 2 ? 32 : 64;
     __shared__ __attribute__((aligned(16))) float s_stage[(kBlock / 64) * STAGE_LANES * PITCH];
     const uint32_t lane = threadIdx.x & 63u;
     float *stage = s_stage + (threadIdx.x >> 6) * (STAGE_LANES * PITCH);   // this wave's slots
-    // density gradients (one per segment: the bulk of the requests) are first summed per cell in a
-    // small block-level table of doubles; entries untouched for an epoch go out as single atomics
+    // The scalar-per-cell contributions -- the density gradient (one per segment: every cell a ray crosses has one,
+    // empty cells included) and the three point-gradient components (one triple per lit segment, for the cell before) --
+    // are first summed per cell in a block-level table of doubles {density, x, y, z}; entries untouched for an epoch go
+    // out as single atomics.  A block's rays meet a cell about ten times (scripts/model_train_batch.py: 0.09 flushes
+    // per segment), so this removes nearly all of these requests; round 2 kept only the density in the table and sent
+    // 3 atomics per lit segment for the point gradient (48 M of the launch's 171 M atomic requests).
     constexpr int DROWS = RF_DTABLE_ROWS;
     constexpr uint32_t kDEpoch = RF_DTABLE_EPOCH;
-    __shared__ double s_dens[DROWS];
+    __shared__ __attribute__((aligned(16))) double s_dens[DROWS * 4];
     __shared__ uint32_t s_dkeys[DROWS];
     __shared__ uint8_t s_dtouch[DROWS];
     for (uint32_t e = threadIdx.x; e < (uint32_t)DROWS; e += kBlock) {
-        s_dens[e] = 0.0;
+        s_dens[4 * e + 0] = 0.0;
+        s_dens[4 * e + 1] = 0.0;
+        s_dens[4 * e + 2] = 0.0;
+        s_dens[4 * e + 3] = 0.0;
         s_dkeys[e] = kNone;
         s_dtouch[e] = (uint8_t)0;
     }
@@ -1627,7 +1617,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                 const int drow = (dact && dv[0] != 0.0f) ? cache_find<DROWS>(s_dkeys, G.cur) : -1;
                 if (drow >= 0) {
                     s_dtouch[drow] = (uint8_t)1;
-                    atomicAdd(s_dens + drow, (double)dv[0]);
+                    atomicAdd(s_dens + 4 * drow, (double)dv[0]);
                 } else if (dact && dv[0] != 0.0f) {
                     grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), dv[0]);
                 }
@@ -1640,7 +1630,14 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                 absorb_stage<2, 3>(lane, G.prev, pact, pv);
                 absorb_stage<4, 3>(lane, G.prev, pact, pv);
                 absorb_stage<8, 3>(lane, G.prev, pact, pv);
-                if (pact) {
+                const int prow = pact ? cache_find<DROWS>(s_dkeys, G.prev) : -1;
+                if (prow >= 0) {
+                    s_dtouch[prow] = (uint8_t)1;
+                    double *dst = s_dens + 4 * prow + 1;
+                    if (pv[0] != 0.0f) atomicAdd(dst + 0, (double)pv[0]);
+                    if (pv[1] != 0.0f) atomicAdd(dst + 1, (double)pv[1]);
+                    if (pv[2] != 0.0f) atomicAdd(dst + 2, (double)pv[2]);
+                } else if (pact) {
                     float *dst = p.points_grad + 3 * (size_t)G.prev;
                     if (pv[0] != 0.0f) grad_add(dst + 0, pv[0]);
                     if (pv[1] != 0.0f) grad_add(dst + 1, pv[1]);
@@ -1648,7 +1645,23 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                 }
             }
             // colour rows: stage lane-major, emit column-major (two rows per pass, a lane per column)
-            const bool lit = G.has && G.row;
+            bool lit = G.has && G.row;
+#if RF_DIRECT_MERGE_ROWS
+            // lanes of the wave in the same cell first merge their rows in registers (DPP xor stages), as the scalar
+            // contributions above do: fewer rows to emit (0.72 per lit segment in the model of this batch)
+            float rowv[SHP];
+            if (ballot(lit) != 0ull) {
+#pragma unroll
+                for (int k = 0; k < SHP; ++k) {
+                    const float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
+                    rowv[k] = (k < NC && lit) ? sh[(k < NC ? k : 0) / 3] * gc : 0.0f;
+                }
+                absorb_stage<1, SHP>(lane, G.cur, lit, rowv);
+                absorb_stage<2, SHP>(lane, G.cur, lit, rowv);
+                absorb_stage<4, SHP>(lane, G.cur, lit, rowv);
+                absorb_stage<8, SHP>(lane, G.cur, lit, rowv);
+            }
+#endif
             if (ballot(lit) != 0ull) {
 #pragma unroll
                 for (int half = 0; half < 64 / STAGE_LANES; ++half) {
@@ -1664,8 +1677,12 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 const int k = 4 * j + c;
+#if RF_DIRECT_MERGE_ROWS
+                                x[c] = rowv[k];
+#else
                                 const float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
                                 x[c] = k < NC ? sh[(k < NC ? k : 0) / 3] * gc : 0.0f;
+#endif
                             }
                             dst4[j] = make_float4(x[0], x[1], x[2], x[3]);
                         }
@@ -1706,10 +1723,18 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                 const uint32_t key = s_dkeys[e];
                 if (key == kNone) continue;
                 if (!block_alive || s_dtouch[e] == (uint8_t)0) {
-                    const float v = (float)s_dens[e];
-                    s_dens[e] = 0.0;
+                    const float v = (float)s_dens[4 * e], gx = (float)s_dens[4 * e + 1];
+                    const float gy = (float)s_dens[4 * e + 2], gz = (float)s_dens[4 * e + 3];
+                    s_dens[4 * e + 0] = 0.0;
+                    s_dens[4 * e + 1] = 0.0;
+                    s_dens[4 * e + 2] = 0.0;
+                    s_dens[4 * e + 3] = 0.0;
                     s_dkeys[e] = kNone;
                     if (v != 0.0f) grad_add(p.attr_grad + (size_t)key * A + (A - 1), v);
+                    float *pg = p.points_grad + 3 * (size_t)key;
+                    if (gx != 0.0f) grad_add(pg + 0, gx);
+                    if (gy != 0.0f) grad_add(pg + 1, gy);
+                    if (gz != 0.0f) grad_add(pg + 2, gz);
                 } else {
                     s_dtouch[e] = (uint8_t)0;
                 }
@@ -2048,19 +2073,12 @@ struct LaunchForward {
     static int run(const FwdParams &p, bool bench, hipStream_t stream) {
         uint32_t nb = launch_blocks(p.grid);
         if (nb == 0) return RF_OK;
-        const bool sync = p.sync_delta > 0.0f;
         if (bench)
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
-        else if (p.stats && sync)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, true, true>), dim3(nb), dim3(kBlock), 0, stream, p);
         else if (p.stats)
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, true>), dim3(nb), dim3(kBlock), 0, stream, p);
-        else if (p.nq && sync)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, true>), dim3(nb), dim3(kBlock), 0, stream, p);
         else if (p.nq)
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false>), dim3(nb), dim3(kBlock), 0, stream, p);
-        else if (sync)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, true>), dim3(nb), dim3(kBlock), 0, stream, p);
         else
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
         return check_launch(bench ? "rf_trace_benchmark" : "rf_trace_forward");
@@ -2225,9 +2243,6 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     p.contribution = static_cast<float *>(point_contribution);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
     p.visit_marks = opts->stats ? opts->visit_marks : nullptr;
-    // depth synchronisation: flat batches only (the lanes of an image tile stay together by themselves)
-    p.sync_delta = (p.grid.img_w == 0u && opts->sync_delta > 0.0f && opts->sync_delta == opts->sync_delta)
-                       ? opts->sync_delta : 0.0f;
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: trail_slots smaller than rf_trail_slots()");
@@ -2290,8 +2305,6 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     p.attr_grad = static_cast<float *>(attribute_grad);
     p.point_error = static_cast<float *>(point_error);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
-    p.sync_delta = (p.grid.img_w == 0u && opts->sync_delta > 0.0f && opts->sync_delta == opts->sync_delta)
-                       ? opts->sync_delta : 0.0f;
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: trail_slots smaller than rf_trail_slots()");

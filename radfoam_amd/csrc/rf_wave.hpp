@@ -107,17 +107,6 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
-// Minimum over all 64 lanes, result in every lane.
-__device__ __forceinline__ float wave_min(float x) {
-    x = __builtin_fminf(x, xor_lane<1>(x));
-    x = __builtin_fminf(x, xor_lane<2>(x));
-    x = __builtin_fminf(x, xor_lane<4>(x));
-    x = __builtin_fminf(x, xor_lane<8>(x));
-    x = __builtin_fminf(x, xor_lane_any<16>(x));
-    x = __builtin_fminf(x, xor_lane_any<32>(x));
-    return x;
-}
-
 // One butterfly stage across lane bit BIT on v[0..n): n >= 2 halves the number of values
 // (lane with the bit clear keeps the even one of each pair), n == 1 just accumulates.
 template <int BIT, int N>

@@ -121,7 +121,6 @@ class _FoamCache:
         self.topo_key = None
         self.refs = None
         self.workspace = None
-        self.spacing = None   # mean cell spacing of the packed foam (sync_cells)
 
     @staticmethod
     def _key(tensors):
@@ -199,11 +198,6 @@ class Pipeline:
         #: batches smaller than this are traced as they come
         self.reorder_min_rays = 16384
         self._order = None
-        #: flat batches: keep the rays of a wave within this many mean cell spacings of the wave's laggard in depth
-        #: (rf_launch_opts.sync_delta; 0 = off).  Scheduling only -- results do not depend on it.
-        self.sync_cells = 0.0
-        #: the same for trace_backward's trail replay alone (None = sync_cells)
-        self.sync_cells_backward = None
 
     def invalidate(self):
         """Forget the cached packed foam, hop trail and ray order of this Pipeline (and free the trail).
@@ -297,7 +291,7 @@ class Pipeline:
         return s
 
     # -- foam packing ---------------------------------------------------------------------------
-    def _launch_opts(self, points, attributes, adjacency, offsets, rays_shape, ext_diff=None, backward=False):
+    def _launch_opts(self, points, attributes, adjacency, offsets, rays_shape, ext_diff=None):
         """Workspace + rf_launch_opts for this call (foam_prepared set on a cache hit)."""
         n = points.numel() // 3
         e = adjacency.numel()
@@ -319,15 +313,6 @@ class Pipeline:
         # as [B, 1, 6] is a flat batch: tiles of it would be mostly empty)
         if len(rays_shape) == 3 and rays_shape[0] >= 16 and rays_shape[1] >= 16:
             opts.image_height, opts.image_width = int(rays_shape[0]), int(rays_shape[1])
-        elif (self.sync_cells > 0 or (self.sync_cells_backward or 0) > 0) and n > 0:
-            # mean cell spacing = (bounding-box volume / N)^(1/3); re-derived (one host read) only when the foam is
-            # packed from scratch, i.e. after a triangulation rebuild -- it barely moves between optimiser steps
-            if self._cache.spacing is None or not (hit or topo):
-                p = points.detach()
-                ext = (p.amax(dim=0) - p.amin(dim=0)).clamp_min(1e-30)
-                self._cache.spacing = float((ext.prod() / n) ** (1.0 / 3.0))
-            k = self.sync_cells_backward if (backward and self.sync_cells_backward is not None) else self.sync_cells
-            opts.sync_delta = float(k) * self._cache.spacing
         # The workspace is about to be (re)packed by the C call: until that call has succeeded the cache
         # must not claim it (a failed or never-issued launch would leave an unpacked workspace behind a
         # valid key).  _foam_done() records it afterwards.
@@ -606,7 +591,7 @@ class Pipeline:
                 out["point_error"] = point_error.to(self._attr_dtype)
             return out
 
-        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape, backward=True)
+        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
         self._ray_order(opts, rays_c, start_c, num_rays)
         tr = self._trail
         if tr is not None and tr["order"] == opts.ray_order and \

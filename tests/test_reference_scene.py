@@ -163,7 +163,7 @@ def _drive(scene_mod, device, n_init=6000, check_oracle=True):
     if check_oracle:
         ref2 = _oracle_forward(model, rays, start, q, contribution=True)
         assert np.array_equal(depth2.detach().cpu().numpy().view(np.uint32), ref2["depth"].view(np.uint32))
-        np.testing.assert_allclose(contrib2.cpu().numpy(), ref2["contribution"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(contrib2.detach().cpu().numpy(), ref2["contribution"], rtol=1e-4, atol=1e-6)
         pts, att, adj, off = (t.detach().cpu().numpy() for t in model.get_trace_data())
         rb = O.trace_backward(sh, pts, att, adj.astype(np.uint32), off.astype(np.uint32), rays.cpu().numpy(),
                               start.cpu().numpy().astype(np.uint32), ref2["rgba"], w.cpu().numpy(),
@@ -217,7 +217,7 @@ def _drive(scene_mod, device, n_init=6000, check_oracle=True):
         assert point_error is not None and point_error.shape == (model.primal_points.shape[0], 1)
         model.optimizer.zero_grad(set_to_none=True)
     assert point_error.shape == (n, 1) and point_contribution.shape == (n, 1)
-    assert float(point_error.sum()) > 0 and float(point_contribution.max()) > 0
+    assert float(point_error.detach().sum()) > 0 and float(point_contribution.detach().max()) > 0
     model.prune_and_densify(point_error, point_contribution, upsample_factor=1.15)
     n2 = model.primal_points.shape[0]
     assert n < n2 <= int(1.15 * n) + 1
