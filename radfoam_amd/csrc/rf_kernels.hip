@@ -1256,10 +1256,7 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 #define RF_BWD_WAVES_D3 3
 #endif
 #ifndef RF_DTABLE_ROWS
-#define RF_DTABLE_ROWS 640
-#endif
-#ifndef RF_DIRECT_MERGE_ROWS
-#define RF_DIRECT_MERGE_ROWS 0
+#define RF_DTABLE_ROWS 768
 #endif
 #ifndef RF_DTABLE_EPOCH
 #define RF_DTABLE_EPOCH 4
@@ -1541,6 +1538,33 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
 }
 
 // ------------------------------------------------------------------------------------------
+// Lock-free write-back cache entry {cell id, fp32 sum} in LDS, one 64-bit word (backward_replay_direct_kernel).
+constexpr unsigned long long kEmptyEntry = (unsigned long long)kNone << 32;
+
+// sum[key] += v in a direct-mapped table of ROWS entries; an entry that holds another cell is taken over and its sum
+// sent to memory (dst[stride * cell]) as one atomic.  One compare-and-swap per attempt: whatever other lanes or waves
+// do to the entry in between only makes the attempt repeat.
+template <int ROWS>
+__device__ __forceinline__ void table_add(unsigned long long *tab, uint32_t key, float v, float *dst, size_t stride) {
+    const uint32_t slot = (((key * 2654435761u) >> 16) * (uint32_t)ROWS) >> 16;
+    unsigned long long old = tab[slot];
+    for (;;) {
+        const uint32_t okey = (uint32_t)(old >> 32);
+        const float sum = okey == key ? __builtin_bit_cast(float, (uint32_t)old) + v : v;
+        const unsigned long long want = ((unsigned long long)key << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, sum);
+        const unsigned long long seen = atomicCAS(&tab[slot], old, want);
+        if (seen == old) {
+            if (okey != key && okey != kNone) {
+                const float evicted = __builtin_bit_cast(float, (uint32_t)old);
+                if (evicted != 0.0f) grad_add(dst + stride * (size_t)okey, evicted);
+            }
+            return;
+        }
+        old = seen;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // MODE 4: trail replay with direct, row-coalesced global atomics -- for flat (training-like) batches.
 //
 // A sparse batch leaves little to combine: even in the coherent order of rf_build_ray_order the 64
@@ -1572,26 +1596,17 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
     float *stage = s_stage + (threadIdx.x >> 6) * (STAGE_LANES * PITCH);   // this wave's slots
     // The scalar-per-cell contributions -- the density gradient (one per segment: every cell a ray crosses has one,
     // empty cells included) and the three point-gradient components (one triple per lit segment, for the cell before) --
-    // are first summed per cell in a block-level table of doubles {density, x, y, z}; entries untouched for an epoch go
-    // out as single atomics.  A block's rays meet a cell about ten times (scripts/model_train_batch.py: 0.09 flushes
-    // per segment), so this removes nearly all of these requests; round 2 kept only the density in the table and sent
-    // 3 atomics per lit segment for the point gradient (48 M of the launch's 171 M atomic requests).
+    // are first summed per cell in block-level write-back caches: four direct-mapped tables (density, x, y, z) of
+    // 64-bit entries {cell, fp32 sum}, updated by one 64-bit compare-and-swap -- add when the entry holds the lane's
+    // cell, take the entry (and send what it held to memory as one atomic) when it holds another.  No locks, no epochs,
+    // and above all NO BLOCK BARRIER in the walk: round 2's table was flushed by all four waves together every four
+    // steps, which tied the waves of a block into lockstep -- twelve waves per CU hid latency like three (the launch
+    // ran 6.1 ms of its 9.9 with every global atomic compiled out).  A block's rays meet a cell about ten times
+    // (scripts/model_train_batch.py), so the tables remove nearly all of these requests.
     constexpr int DROWS = RF_DTABLE_ROWS;
-    constexpr uint32_t kDEpoch = RF_DTABLE_EPOCH;
-    __shared__ __attribute__((aligned(16))) double s_dens[DROWS * 4];
-    __shared__ uint32_t s_dkeys[DROWS];
-    __shared__ uint8_t s_dtouch[DROWS];
-    for (uint32_t e = threadIdx.x; e < (uint32_t)DROWS; e += kBlock) {
-        s_dens[4 * e + 0] = 0.0;
-        s_dens[4 * e + 1] = 0.0;
-        s_dens[4 * e + 2] = 0.0;
-        s_dens[4 * e + 3] = 0.0;
-        s_dkeys[e] = kNone;
-        s_dtouch[e] = (uint8_t)0;
-    }
+    __shared__ unsigned long long s_tab[4][DROWS];
+    for (uint32_t e = threadIdx.x; e < (uint32_t)(4 * DROWS); e += kBlock) (&s_tab[0][0])[e] = kEmptyEntry;
     __syncthreads();
-    uint32_t it = 0;
-    bool block_alive = true;
 
     TrailWalker<DEG, HALF, QUANT> W;
     W.init(p);
@@ -1599,14 +1614,11 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
 
     StepGrad G;
     clear_step(G);
-    while (block_alive) {
-      if (ballot(W.alive) != 0ull) {
+    while (ballot(W.alive) != 0ull) {
         W.step(p, G);
 
         if (ballot(G.has) != 0ull) {
-            // density gradient: lanes of the wave in the same cell merged (DPP xor stages), then one
-            // scattered atomic per remaining lane -- these single-float atomics are the bulk of the
-            // requests (every segment has one): 17.7 ms without the merge, 13.2 ms with it
+            // density gradient: lanes of the wave in the same cell merged (DPP xor stages), then into the block's table
             {
                 bool dact = G.has;
                 float dv[1] = {G.dL_ds};
@@ -1614,13 +1626,8 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                 absorb_stage<2, 1>(lane, G.cur, dact, dv);
                 absorb_stage<4, 1>(lane, G.cur, dact, dv);
                 absorb_stage<8, 1>(lane, G.cur, dact, dv);
-                const int drow = (dact && dv[0] != 0.0f) ? cache_find<DROWS>(s_dkeys, G.cur) : -1;
-                if (drow >= 0) {
-                    s_dtouch[drow] = (uint8_t)1;
-                    atomicAdd(s_dens + 4 * drow, (double)dv[0]);
-                } else if (dact && dv[0] != 0.0f) {
-                    grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), dv[0]);
-                }
+                if (dact && dv[0] != 0.0f)
+                    table_add<DROWS>(s_tab[0], G.cur, dv[0], p.attr_grad + (A - 1), (size_t)A);
             }
             // point gradient of the previous cell
             if (ballot(G.has && G.pg_on) != 0ull) {
@@ -1630,38 +1637,14 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                 absorb_stage<2, 3>(lane, G.prev, pact, pv);
                 absorb_stage<4, 3>(lane, G.prev, pact, pv);
                 absorb_stage<8, 3>(lane, G.prev, pact, pv);
-                const int prow = pact ? cache_find<DROWS>(s_dkeys, G.prev) : -1;
-                if (prow >= 0) {
-                    s_dtouch[prow] = (uint8_t)1;
-                    double *dst = s_dens + 4 * prow + 1;
-                    if (pv[0] != 0.0f) atomicAdd(dst + 0, (double)pv[0]);
-                    if (pv[1] != 0.0f) atomicAdd(dst + 1, (double)pv[1]);
-                    if (pv[2] != 0.0f) atomicAdd(dst + 2, (double)pv[2]);
-                } else if (pact) {
-                    float *dst = p.points_grad + 3 * (size_t)G.prev;
-                    if (pv[0] != 0.0f) grad_add(dst + 0, pv[0]);
-                    if (pv[1] != 0.0f) grad_add(dst + 1, pv[1]);
-                    if (pv[2] != 0.0f) grad_add(dst + 2, pv[2]);
+                if (pact) {
+                    if (pv[0] != 0.0f) table_add<DROWS>(s_tab[1], G.prev, pv[0], p.points_grad + 0, (size_t)3);
+                    if (pv[1] != 0.0f) table_add<DROWS>(s_tab[2], G.prev, pv[1], p.points_grad + 1, (size_t)3);
+                    if (pv[2] != 0.0f) table_add<DROWS>(s_tab[3], G.prev, pv[2], p.points_grad + 2, (size_t)3);
                 }
             }
             // colour rows: stage lane-major, emit column-major (two rows per pass, a lane per column)
-            bool lit = G.has && G.row;
-#if RF_DIRECT_MERGE_ROWS
-            // lanes of the wave in the same cell first merge their rows in registers (DPP xor stages), as the scalar
-            // contributions above do: fewer rows to emit (0.72 per lit segment in the model of this batch)
-            float rowv[SHP];
-            if (ballot(lit) != 0ull) {
-#pragma unroll
-                for (int k = 0; k < SHP; ++k) {
-                    const float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
-                    rowv[k] = (k < NC && lit) ? sh[(k < NC ? k : 0) / 3] * gc : 0.0f;
-                }
-                absorb_stage<1, SHP>(lane, G.cur, lit, rowv);
-                absorb_stage<2, SHP>(lane, G.cur, lit, rowv);
-                absorb_stage<4, SHP>(lane, G.cur, lit, rowv);
-                absorb_stage<8, SHP>(lane, G.cur, lit, rowv);
-            }
-#endif
+            const bool lit = G.has && G.row;
             if (ballot(lit) != 0ull) {
 #pragma unroll
                 for (int half = 0; half < 64 / STAGE_LANES; ++half) {
@@ -1677,34 +1660,45 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 const int k = 4 * j + c;
-#if RF_DIRECT_MERGE_ROWS
-                                x[c] = rowv[k];
-#else
                                 const float gc = (k % 3 == 0) ? G.dLr : ((k % 3 == 1) ? G.dLg : G.dLb);
                                 x[c] = k < NC ? sh[(k < NC ? k : 0) / 3] * gc : 0.0f;
-#endif
                             }
                             dst4[j] = make_float4(x[0], x[1], x[2], x[3]);
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    const uint32_t col0 = lane & 31u;
-                    while (todo != 0ull) {
-                        const uint32_t b0 = (uint32_t)__builtin_ctzll(todo);
-                        todo &= todo - 1ull;
-                        uint32_t b1 = 64u;
-                        if (todo != 0ull) {
-                            b1 = (uint32_t)__builtin_ctzll(todo);
+                    if constexpr (NC > 32) {
+                        // a row wider than a half-wave goes out as ONE instruction, a lane per column: split at column
+                        // 32 the line that holds the boundary was requested twice (5 requests per 192-byte row, 4 now)
+                        while (todo != 0ull) {
+                            const uint32_t src = (uint32_t)__builtin_ctzll(todo);
                             todo &= todo - 1ull;
-                        }
-                        const uint32_t src = lane < 32u ? b0 : b1;       // the lane whose row this half-wave emits
-                        const uint32_t cell = __shfl(G.cur, (int)(src & 63u), 64);
-                        if (src < 64u) {
+                            const uint32_t cell = readlane(G.cur, (int)src);
                             const uint32_t slot = src & (uint32_t)(STAGE_LANES - 1);
-                            for (uint32_t col = col0; col < (uint32_t)NC; col += 32u) {
-                                const float v = stage[slot * PITCH + col];
-                                if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * A + col, v);
+                            if (lane < (uint32_t)NC) {
+                                const float v = stage[slot * PITCH + lane];
+                                if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * A + lane, v);
+                            }
+                        }
+                    } else {
+                        const uint32_t col0 = lane & 31u;
+                        while (todo != 0ull) {
+                            const uint32_t b0 = (uint32_t)__builtin_ctzll(todo);
+                            todo &= todo - 1ull;
+                            uint32_t b1 = 64u;
+                            if (todo != 0ull) {
+                                b1 = (uint32_t)__builtin_ctzll(todo);
+                                todo &= todo - 1ull;
+                            }
+                            const uint32_t src = lane < 32u ? b0 : b1;       // the lane whose row this half-wave emits
+                            const uint32_t cell = __shfl(G.cur, (int)(src & 63u), 64);
+                            if (src < 64u) {
+                                const uint32_t slot = src & (uint32_t)(STAGE_LANES - 1);
+                                if (col0 < (uint32_t)NC) {
+                                    const float v = stage[slot * PITCH + col0];
+                                    if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * A + col0, v);
+                                }
                             }
                         }
                     }
@@ -1715,32 +1709,17 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
         G.has = false;
         G.row = false;
         G.pg_on = false;
-      }
-        it++;
-        if ((it & (kDEpoch - 1u)) == 0u) {
-            block_alive = __syncthreads_or(W.alive ? 1 : 0) != 0;
-            for (uint32_t e = threadIdx.x; e < (uint32_t)DROWS; e += kBlock) {
-                const uint32_t key = s_dkeys[e];
-                if (key == kNone) continue;
-                if (!block_alive || s_dtouch[e] == (uint8_t)0) {
-                    const float v = (float)s_dens[4 * e], gx = (float)s_dens[4 * e + 1];
-                    const float gy = (float)s_dens[4 * e + 2], gz = (float)s_dens[4 * e + 3];
-                    s_dens[4 * e + 0] = 0.0;
-                    s_dens[4 * e + 1] = 0.0;
-                    s_dens[4 * e + 2] = 0.0;
-                    s_dens[4 * e + 3] = 0.0;
-                    s_dkeys[e] = kNone;
-                    if (v != 0.0f) grad_add(p.attr_grad + (size_t)key * A + (A - 1), v);
-                    float *pg = p.points_grad + 3 * (size_t)key;
-                    if (gx != 0.0f) grad_add(pg + 0, gx);
-                    if (gy != 0.0f) grad_add(pg + 1, gy);
-                    if (gz != 0.0f) grad_add(pg + 2, gz);
-                } else {
-                    s_dtouch[e] = (uint8_t)0;
-                }
-            }
-            __syncthreads();
-        }
+    }
+    // every wave of the block is done: what the tables still hold goes to memory
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < (uint32_t)(4 * DROWS); e += kBlock) {
+        const unsigned long long ent = (&s_tab[0][0])[e];
+        const uint32_t key = (uint32_t)(ent >> 32);
+        const float v = __builtin_bit_cast(float, (uint32_t)ent);
+        if (key == kNone || v == 0.0f) continue;
+        const uint32_t t = e / (uint32_t)DROWS;
+        if (t == 0u) grad_add(p.attr_grad + (size_t)key * A + (A - 1), v);
+        else grad_add(p.points_grad + 3 * (size_t)key + (t - 1u), v);
     }
 }
 
