@@ -171,9 +171,17 @@ class Pipeline:
         self._cache = _FoamCache()
         #: reuse the packed foam between calls while the inputs are unchanged
         self.cache_foam = True
-        #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics, 3 block cache, 4 direct row atomics
-        #: (rf_launch_opts.backward_mode)
+        #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics, 3 block cache, 4 direct row atomics, 5 = 4 with the
+        #: colour rows sorted by cell and summed instead of scattered (rf_launch_opts.backward_mode).  Auto: 3 for
+        #: image-shaped batches, 5 for flat ones (4 when gather_rows is off).
         self.backward_mode = 0
+        #: flat batches: give trace_backward the scratch of mode 5 (records of the colour-row gradients, sorted and
+        #: summed; 40 bytes per record + the sort's temporary).  The call then synchronises the stream once.
+        self.gather_rows = True
+        #: records the scratch is sized for; grown to what a call reports when it ran out (the excess of that call went
+        #: through atomics: same gradients, slower)
+        self.gather_capacity = 0
+        self._gather_ws = None
         #: trace_forward records the cell every hop enters so that a trace_backward call on the same
         #: inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).  Costs
         #: trail_steps * 4 bytes per ray of HBM (2.1 GB for a 1080p frame at 256 steps), so:
@@ -205,6 +213,7 @@ class Pipeline:
         self._cache.clear()
         self._trail = None
         self._order = None
+        self._gather_ws = None
 
     def _wants_trail(self, points, attributes) -> bool:
         """"auto": will a trace_backward follow this forward?  Inside an autograd.Function.forward grad mode is off and
@@ -601,6 +610,20 @@ class Pipeline:
             opts.trail_hops = tr["hops"].data_ptr()
             opts.trail_cap = tr["cap"]
             opts.trail_slots = tr["slots"]
+        produced = None
+        if self.gather_rows and opts.trail and not opts.image_width and int(self.backward_mode) in (0, 5):
+            cap = int(self.gather_capacity) or max(1 << 16, 32 * num_rays)
+            cap = min(cap, 0x7FFFFFFF)
+            need = int(self._lib.rf_gather_workspace_bytes(cap))
+            ws = self._gather_ws
+            if ws is None or ws.numel() < need or ws.device != dev:
+                ws = self._gather_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            produced = C.c_uint32(0)
+            opts.gather_workspace = ws.data_ptr()
+            opts.gather_workspace_bytes = ws.numel()
+            opts.gather_capacity = cap
+            opts.gather_count = C.pointer(produced)
+            self.gather_capacity = cap
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_backward(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),
@@ -610,6 +633,10 @@ class Pipeline:
                 _ptr(attr_grad), _ptr(point_error), C.byref(opts), _stream_ptr(dev))
         _lib.check(rc)
         self._foam_done(opts)
+        if produced is not None:
+            self.last_gather_records = int(produced.value)
+            if produced.value > self.gather_capacity:   # ran out: the next call gets room for this many and a margin
+                self.gather_capacity = int(produced.value * 1.25) + 1024
         if self.free_trail_after_backward:
             self._trail = None
 

@@ -146,7 +146,7 @@ def _backward_case(foam_factory, d, seed, image, quantiles, with_error, n_points
     return fm, rays, starts, q, dg, g, err, fwd, ref
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("trail", ["rewalk", "replay", "short"])
 @pytest.mark.parametrize("d,image,quantiles,with_error", [
     (0, True, False, False), (1, False, True, True), (2, True, True, False), (2, False, False, True),
@@ -622,6 +622,41 @@ def test_hip_matches_reference_source_goldens(path):
         if k in fwd:
             fwd[k] = fwd[k].view(np.uint32)
     check_against_golden(z, fwd, bwd, diff.cpu().numpy(), bench, half)
+
+
+@pytest.mark.parametrize("capacity", [0, 1000, 7])
+def test_gather_backward_of_a_flat_batch(foam_factory, capacity):
+    """Backward mode 5 (the default for flat batches): colour-row gradients appended as records, sorted by cell and summed.
+    capacity 0 = the pipeline's own sizing; 1000 / 7 = far too small on purpose: the records that do not fit go through
+    atomics, the gradients are the same, and the pipeline grows its scratch to what the call reported."""
+    d = 3
+    fm = foam_factory(6000, d, 78)
+    rays, starts = H.random_rays(fm, 30_000, seed=6)
+    g = np.random.default_rng(10).normal(size=(30_000, 4)).astype(np.float32)
+    args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    fwd = O.trace_forward(*args, rays, starts)
+    ref = O.trace_backward(*args, rays, starts, fwd["rgba"], g)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    t = lambda x: torch.from_numpy(x).to(DEV)
+    pipe = _pipeline(d)
+    assert pipe.gather_rows and pipe.backward_mode == 0
+    pipe.gather_capacity = capacity
+    f = pipe.trace_forward(p, a, adj, off, t(rays), t(starts))
+    out = pipe.trace_backward(p, a, adj, off, t(rays), t(starts), f["rgba"], t(g))
+    assert pipe.last_gather_records > 1000            # lit segments of the batch: the records of this call
+    if capacity:
+        assert pipe.gather_capacity >= pipe.last_gather_records   # grown for the next call
+    for key in ("points_grad", "attr_grad"):
+        ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+        assert ok and rel < 1e-5, (key, rel, worst)
+    # mode 4 on the same inputs: the same sums in another order
+    pipe4 = _pipeline(d)
+    pipe4.backward_mode = 4
+    f4 = pipe4.trace_forward(p, a, adj, off, t(rays), t(starts))
+    out4 = pipe4.trace_backward(p, a, adj, off, t(rays), t(starts), f4["rgba"], t(g))
+    for key in ("points_grad", "attr_grad"):
+        ok, rel, worst = H.grad_close(out[key].cpu().numpy(), out4[key].cpu().numpy())
+        assert ok and rel < 1e-5, (key, rel, worst)
 
 
 def test_shuffled_batch_is_traced_in_a_coherent_order(foam_factory):
