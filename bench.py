@@ -389,6 +389,7 @@ def main():
     bounds = None
     for i in range(args.warmup):
         step(False)
+        sync()   # lets the pipeline see the longest ray of the batch before the next step sizes its hop trail
         if i == 0 and strong and W["kind"] == "image" and not args.no_rebalance:
             bounds = tracer.rebalance(last["out"]["num_intersections"], rays.shape[0])
     sync()

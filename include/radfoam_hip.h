@@ -67,10 +67,8 @@ typedef struct rf_launch_opts {
     uint32_t image_height;    /*   own an 8x8 pixel tile.  0,0 = treat rays as a flat list            */
     uint32_t backward_mode;   /* rf_trace_backward only: 0 = auto, 1 = per-lane atomics, 2 = wave     */
                               /*   pre-reduced atomics, 3 = block-level LDS write-combining, 4 =      */
-                              /*   direct row-coalesced atomics, 5 = 4 with the colour rows sorted    */
-                              /*   and summed instead of scattered (gather_* below; without them: 4). */
-                              /*   3-5 need the trail and fall back to 2 without it; auto = 3 for     */
-                              /*   image-shaped batches, 4 / 5 for flat ones (5 when gather_* is set) */
+                              /*   direct row-coalesced atomics (3, 4 need the trail and fall back to */
+                              /*   2 without it; auto = 3 for image-shaped batches, 4 for flat ones)  */
     uint64_t *stats;          /* optional device uint64[8]: walk counters for the roofline figure     */
                               /*   [0] cells scanned [1] faces scanned [2] hops [3] segments          */
                               /*   [4] lit segments; accumulated with atomics, caller zeroes          */
@@ -92,18 +90,6 @@ typedef struct rf_launch_opts {
     /* any ray scans cell i (the caller zeroes it).  Feeds the compulsory-traffic floor of bench.py's   */
     /* roofline: bytes of the distinct cells, face lists and colour rows a frame touches at least once. */
     uint8_t *visit_marks;
-    /* rf_trace_backward, backward_mode 5 (flat batches with a trail): the colour-row gradients -- 3B floats per lit   */
-    /* segment, the bulk of the scatter -- are not added with atomics one segment at a time; every lit segment        */
-    /* appends a 16-byte record {dL/drgb, ray} and its cell id, the records are sorted by cell (device radix sort) and  */
-    /* summed row by row, one coalesced atomic row per run of 64 sorted records.  gather_workspace: device scratch of */
-    /* at least rf_gather_workspace_bytes(gather_capacity); gather_capacity: records it has room for -- segments       */
-    /* beyond it fall back to per-lane atomics, so any capacity gives the same gradients; gather_count: optional HOST  */
-    /* word that receives the number of records the call produced (to size the next call).  The call synchronises the */
-    /* stream once (the record count has to reach the host before the sort can be sized).                              */
-    void *gather_workspace;
-    size_t gather_workspace_bytes;
-    uint32_t gather_capacity;
-    uint32_t *gather_count;
 } rf_launch_opts;
 
 /* Last error message of the calling thread ("" if none). */
@@ -249,8 +235,6 @@ int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_
  * No counterpart in the reference, whose kernels take the batch as it comes. */
 size_t rf_ray_order_workspace_bytes(uint32_t num_rays);
 
-/* Scratch of backward_mode 5 for `capacity` records (rf_launch_opts::gather_workspace). */
-size_t rf_gather_workspace_bytes(uint32_t capacity);
 int rf_build_ray_order(const float *rays, const uint32_t *start_point_index, uint32_t num_rays,
                        uint32_t *ray_order, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -57,10 +57,6 @@ class LaunchOpts(C.Structure):
         ("trail_slots", C.c_uint32),
         ("ray_order", C.c_void_p),
         ("visit_marks", C.c_void_p),
-        ("gather_workspace", C.c_void_p),
-        ("gather_workspace_bytes", C.c_size_t),
-        ("gather_capacity", C.c_uint32),
-        ("gather_count", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -86,7 +82,6 @@ SYMBOLS = {
     "rf_nearest_point": (_INT, [_P, _U32, _P, _U32, _P, _P, _P]),
     "rf_farthest_neighbor": (_INT, [_P, _U32, _P, _P, _P, _P, _P]),
     "rf_ray_order_workspace_bytes": (C.c_size_t, [_U32]),
-    "rf_gather_workspace_bytes": (C.c_size_t, [_U32]),
     "rf_build_ray_order": (_INT, [_P, _P, _U32, _P, _P, C.c_size_t, _P]),
     "rf_adjacency_workspace_bytes": (C.c_size_t, [_U32]),
     "rf_build_adjacency": (_INT, [_P, _U32, _U32, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -21,7 +21,6 @@
 #include "../../include/radfoam_hip.h"
 #include "rf_foam.hpp"
 #include "rf_host.hpp"
-#include "rf_sort.hpp"
 
 namespace rf {
 
@@ -142,22 +141,6 @@ static AdjacencyLayout adjacency_layout(uint32_t num_tets) {
     L.temp = L.count + 256;
     L.total = L.temp + align_up(L.temp_bytes, 256);
     return L;
-}
-
-size_t gather_sort_temp_bytes(uint32_t capacity) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint4 *)nullptr,
-                                    (uint4 *)nullptr, (size_t)capacity, 0, 32, (hipStream_t)0);
-    return bytes;
-}
-
-int gather_sort(const uint32_t *keys_in, uint32_t *keys_out, const uint4 *recs_in, uint4 *recs_out, uint32_t count,
-                unsigned key_bits, void *temp, size_t temp_bytes, hipStream_t stream) {
-    size_t bytes = temp_bytes;
-    if (rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, recs_in, recs_out, (size_t)count, 0, key_bits,
-                                  stream) != hipSuccess)
-        return fail(RF_ERR_LAUNCH, "rf_trace_backward: radix sort of the gradient records failed");
-    return RF_OK;
 }
 
 }  // namespace rf

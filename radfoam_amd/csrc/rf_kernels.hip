@@ -42,7 +42,6 @@
 #include "rf_foam.hpp"
 #include "rf_host.hpp"
 #include "rf_math.hpp"
-#include "rf_sort.hpp"
 #include "rf_wave.hpp"
 
 namespace rf {
@@ -111,11 +110,6 @@ struct BwdParams {
     uint32_t trail_cap, trail_slots;
     unsigned long long *stats;   // optional scatter counters (experiments): [0] row flushes [1] values flushed
                                  // [2] lane contributions that bypassed the block cache [3] cached lane contributions
-    // mode 5: colour-row gradients appended as records {dL/drgb, ray} + their cell, sorted and summed afterwards
-    uint32_t *gather_counter;    // records appended so far (may run past gather_capacity: the excess went to atomics)
-    uint32_t *gather_keys;       // [gather_capacity] cell of each record
-    uint4 *gather_recs;          // [gather_capacity] {dLr, dLg, dLb (float bits), ray index}
-    uint32_t gather_capacity;
 };
 
 constexpr int kBlock = 256;
@@ -1303,11 +1297,12 @@ struct TrailWalker {
     BwdRay R;
     float sh[NB];
     float4 head, q0;
-    uint32_t cur, hops, recorded, i, n, id0, id1, slot, ray;
+    uint32_t cur, hops, recorded, i, n, id0, id1, slot;
     size_t slots;
     bool alive;
 
     __device__ __forceinline__ void init(const BwdParams &p) {
+        uint32_t ray;
         alive = map_ray(p.grid, ray, slot);
         const FoamView &fv = p.foam;
         slots = p.trail_slots;
@@ -1519,11 +1514,7 @@ __device__ __forceinline__ void table_add(unsigned long long *tab, uint32_t key,
 // density gradient -- one value per segment, 10 of the 13 ms when sent directly -- still goes through
 // a block-level table: 768 cells x one double, same-cell lanes pre-merged by DPP, entries untouched
 // for 4 steps flushed as single atomics (13.1 -> 8.1 ms).
-// GATHER (mode 5): the colour rows are not emitted at all here; every lit segment appends a 16-byte record {dL/drgb, ray}
-// and its cell to a stream (one wave-aggregated counter bump per wave-step, coalesced stores), which gather_rows_kernel
-// sums after a device sort by cell -- a lit cell of this batch is crossed by some fifty rays, so a run of 64 sorted
-// records is one or two cells and leaves as one or two coalesced atomic rows instead of 64 scattered ones.
-template <int DEG, bool HALF, bool QUANT, bool GATHER = false>
+template <int DEG, bool HALF, bool QUANT>
 __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void backward_replay_direct_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
     constexpr int A = 1 + 3 * NB;
@@ -1534,7 +1525,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
     // block: with the density table two blocks fit a CU (2 waves/SIMD, and every cell gather of a sparse batch
     // is its own cache miss to hide).  Staging one half-wave after the other halves that (4 blocks per CU).
     constexpr int STAGE_LANES = DEG >= 2 ? RF_STAGE_LANES_D3 : 64;   // 64, 32 or 16
-    __shared__ __attribute__((aligned(16))) float s_stage[GATHER ? 4 : (kBlock / 64) * STAGE_LANES * PITCH];
+    __shared__ __attribute__((aligned(16))) float s_stage[(kBlock / 64) * STAGE_LANES * PITCH];
     const uint32_t lane = threadIdx.x & 63u;
     float *stage = s_stage + (threadIdx.x >> 6) * (STAGE_LANES * PITCH);   // this wave's slots
     // The scalar-per-cell contributions -- the density gradient (one per segment: every cell a ray crosses has one,
@@ -1588,27 +1579,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
             }
             // colour rows: stage lane-major, emit column-major (two rows per pass, a lane per column)
             const bool lit = G.has && G.row;
-            if constexpr (GATHER) {
-                const unsigned long long m = ballot(lit);
-                if (m != 0ull) {
-                    const int leader = __builtin_ctzll(m);
-                    uint32_t base = 0;
-                    if ((int)lane == leader) base = atomicAdd(p.gather_counter, (uint32_t)__builtin_popcountll(m));
-                    base = readlane(base, leader);
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (lit) {
-                        const uint32_t pos = base + rank;
-                        if (pos < p.gather_capacity) {
-                            p.gather_keys[pos] = G.cur;
-                            p.gather_recs[pos] = make_uint4(__builtin_bit_cast(uint32_t, G.dLr), __builtin_bit_cast(uint32_t, G.dLg),
-                                                            __builtin_bit_cast(uint32_t, G.dLb), W.ray);
-                        } else {   // no room left in the caller's scratch: this row goes the slow way, the sums stay right
-                            add_row_per_lane<NB>(p.attr_grad + (size_t)G.cur * A, sh, G.dLr, G.dLg, G.dLb);
-                        }
-                    }
-                }
-            } else if (ballot(lit) != 0ull) {
+            if (ballot(lit) != 0ull) {
 #pragma unroll
                 for (int half = 0; half < 64 / STAGE_LANES; ++half) {
                     const bool mine = lit && (STAGE_LANES == 64 || (int)(lane / (uint32_t)STAGE_LANES) == half);
@@ -1683,74 +1654,6 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
         const uint32_t t = e / (uint32_t)DROWS;
         if (t == 0u) grad_add(p.attr_grad + (size_t)key * A + (A - 1), v);
         else grad_add(p.points_grad + 3 * (size_t)key + (t - 1u), v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// MODE 5, second half: the sorted records -> attr_grad.  A lane takes one record: the ray's SH basis is recomputed from
-// its direction exactly as the walk kernels form it, the lanes of the wave that hold the same cell (sorted: a run of
-// neighbouring lanes) sum their rows with the transposing butterfly of rf_wave.hpp and the run leaves as ONE coalesced
-// atomic row, a lane per column.
-#ifndef RF_GATHER_ITERS
-#define RF_GATHER_ITERS 8
-#endif
-
-template <int DEG>
-__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const uint32_t *__restrict__ keys, const uint4 *__restrict__ recs,
-                                                             uint32_t count, const float *__restrict__ rays,
-                                                             float *__restrict__ attr_grad) {
-    constexpr int NB = sh_dim(DEG);
-    constexpr int A = 1 + 3 * NB;
-    constexpr int NC = 3 * NB;
-    constexpr int NV = pow2_at_least(NC);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * (uint32_t)kBlock + threadIdx.x) >> 6;
-    const uint32_t first = wave * 64u * (uint32_t)RF_GATHER_ITERS;
-    for (uint32_t it = 0; it < (uint32_t)RF_GATHER_ITERS; ++it) {
-        const uint32_t i = first + it * 64u + lane;
-        if (first + it * 64u >= count) break;
-        const bool has = i < count;
-        uint32_t key = kNone;
-        float dLr = 0.0f, dLg = 0.0f, dLb = 0.0f;
-        float sh[NB];
-        float dx = 0.0f, dy = 0.0f, dz = 1.0f;
-        if (has) {
-            key = keys[i];
-            const uint4 r = recs[i];
-            dLr = __builtin_bit_cast(float, r.x);
-            dLg = __builtin_bit_cast(float, r.y);
-            dLb = __builtin_bit_cast(float, r.z);
-            const float *rp = rays + (size_t)r.w * 6 + 3;
-            dx = rp[0];
-            dy = rp[1];
-            dz = rp[2];
-            const float nrm = sqrtf(dot3(dx, dy, dz, dx, dy, dz));   // as load_backward_ray
-            dx = dx / nrm;
-            dy = dy / nrm;
-            dz = dz / nrm;
-        }
-        sh_basis<DEG>(dx, dy, dz, sh);
-        unsigned long long todo = ballot(has);
-        while (todo != 0ull) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t c = readlane(key, leader);
-            const bool mine = has && key == c;
-            const unsigned long long same = ballot(mine);
-            if (__builtin_popcountll(same) <= 2) {
-                if (mine) add_row_per_lane<NB>(attr_grad + (size_t)c * A, sh, dLr, dLg, dLb);
-            } else {
-                float v[NV];
-                const float mr = mine ? dLr : 0.0f, mg = mine ? dLg : 0.0f, mb = mine ? dLb : 0.0f;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) {
-                    const float gc = (k % 3 == 0) ? mr : ((k % 3 == 1) ? mg : mb);
-                    v[k] = k < NC ? sh[(k < NC ? k : 0) / 3] * gc : 0.0f;
-                }
-                const float tot = transpose_reduce<NV>(v, lane);
-                if (lane < (uint32_t)NC && tot != 0.0f) grad_add(attr_grad + (size_t)c * A + lane, tot);
-            }
-            todo &= ~same;
-        }
     }
 }
 
@@ -2111,11 +2014,6 @@ struct LaunchBackward {
                     hipLaunchKernelGGL((backward_replay_direct_kernel<DEG, HALF, true>), dim3(nb), dim3(kBlock), 0, stream, p);
                 else
                     hipLaunchKernelGGL((backward_replay_direct_kernel<DEG, HALF, false>), dim3(nb), dim3(kBlock), 0, stream, p);
-            } else if (mode == 5) {
-                if (p.nq)
-                    hipLaunchKernelGGL((backward_replay_direct_kernel<DEG, HALF, true, true>), dim3(nb), dim3(kBlock), 0, stream, p);
-                else
-                    hipLaunchKernelGGL((backward_replay_direct_kernel<DEG, HALF, false, true>), dim3(nb), dim3(kBlock), 0, stream, p);
             } else if (p.nq)
                 hipLaunchKernelGGL((backward_replay_cached_kernel<DEG, HALF, true>), dim3(nb), dim3(kBlock), 0, stream, p);
             else
@@ -2134,42 +2032,6 @@ struct LaunchBackward {
         return check_launch("rf_trace_backward");
     }
 };
-
-template <int DEG, bool HALF>
-struct LaunchGatherRows {
-    static int run(const uint32_t *keys, const uint4 *recs, uint32_t count, const float *rays, float *attr_grad,
-                   hipStream_t stream) {
-        const uint32_t per_block = (uint32_t)(kBlock / 64) * 64u * (uint32_t)RF_GATHER_ITERS;
-        const uint32_t nb = (count + per_block - 1u) / per_block;
-        if (nb == 0) return RF_OK;
-        hipLaunchKernelGGL(gather_rows_kernel<DEG>, dim3(nb), dim3(kBlock), 0, stream, keys, recs, count, rays, attr_grad);
-        return check_launch("rf_trace_backward (gather rows)");
-    }
-};
-
-// scratch of mode 5: [counter | keys a | keys b | records a | records b | sort temporary]
-struct GatherLayout {
-    size_t counter, keys_a, keys_b, recs_a, recs_b, temp, temp_bytes, total;
-};
-
-static GatherLayout gather_layout(uint32_t capacity) {
-    GatherLayout L{};
-    size_t at = 0;
-    auto take = [&](size_t bytes) {
-        const size_t here = at;
-        at += align_up(bytes, 256);
-        return here;
-    };
-    L.counter = take(256);
-    L.keys_a = take((size_t)capacity * 4);
-    L.keys_b = take((size_t)capacity * 4);
-    L.recs_a = take((size_t)capacity * 16);
-    L.recs_b = take((size_t)capacity * 16);
-    L.temp_bytes = gather_sort_temp_bytes(capacity);
-    L.temp = take(L.temp_bytes);
-    L.total = at;
-    return L;
-}
 
 static RayGrid make_grid(uint32_t num_rays, const rf_launch_opts *opts) {
     RayGrid g{num_rays, 0u, 0u, nullptr};
@@ -2202,8 +2064,6 @@ uint32_t rf_trail_slots(uint32_t num_rays, uint32_t image_width, uint32_t image_
     o.image_height = image_height;
     return num_tiles(make_grid(num_rays, &o)) * (uint32_t)kBlock;
 }
-
-size_t rf_gather_workspace_bytes(uint32_t capacity) { return capacity ? gather_layout(capacity).total : 0; }
 
 size_t rf_workspace_bytes(uint32_t num_points, uint32_t point_adjacency_size, int sh_degree,
                           int attr_type) {
@@ -2328,8 +2188,8 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_point_indices || !depth_grad))
         return fail(RF_ERR_INVALID_ARGUMENT, "depth_grad must be provided if depth_quantiles is provided");
-    if (opts->backward_mode > 5u)
-        return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0..5");
+    if (opts->backward_mode > 4u)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0..4");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -2370,39 +2230,9 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     // 0 = auto: with a trail to replay, the block cache for image-shaped batches (dense: many rays per
     // cell and tile) and direct row atomics for flat ones; wave-reduced scatter without a trail
     int mode = (int)opts->backward_mode;
-    const bool can_gather = opts->gather_workspace && opts->gather_capacity;
-    if (mode == 0) mode = p.trail ? (p.grid.img_w ? 3 : (can_gather ? 5 : 4)) : 2;
-    if (mode == 5 && !can_gather) mode = 4;
-    if ((mode == 3 || mode == 4 || mode == 5) && !p.trail) mode = 2;
-    if (opts->gather_count) *opts->gather_count = 0u;
-    if (mode != 5) return dispatch<LaunchBackward>(sh_degree, half, p, mode, s);
-
-    // ---- mode 5: walk (records appended), count to the host, sort by cell, sum the runs
-    const GatherLayout G = gather_layout(opts->gather_capacity);
-    if (opts->gather_workspace_bytes < G.total)
-        return fail(RF_ERR_WORKSPACE, "gather_workspace smaller than rf_gather_workspace_bytes(gather_capacity)");
-    char *gb = static_cast<char *>(opts->gather_workspace);
-    p.gather_counter = reinterpret_cast<uint32_t *>(gb + G.counter);
-    p.gather_keys = reinterpret_cast<uint32_t *>(gb + G.keys_a);
-    p.gather_recs = reinterpret_cast<uint4 *>(gb + G.recs_a);
-    p.gather_capacity = opts->gather_capacity;
-    if (hipMemsetAsync(p.gather_counter, 0, 4, s) != hipSuccess) return check_launch("rf_trace_backward (gather counter)");
-    int rc = dispatch<LaunchBackward>(sh_degree, half, p, 5, s);
-    if (rc != RF_OK) return rc;
-    uint32_t produced = 0;
-    if (hipMemcpyAsync(&produced, p.gather_counter, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess)
-        return check_launch("rf_trace_backward (gather count)");
-    if (opts->gather_count) *opts->gather_count = produced;
-    const uint32_t stored = produced < opts->gather_capacity ? produced : opts->gather_capacity;
-    if (stored == 0) return RF_OK;
-    unsigned key_bits = 1;
-    while (key_bits < 32u && (1ull << key_bits) < (unsigned long long)num_points) ++key_bits;
-    uint32_t *keys_sorted = reinterpret_cast<uint32_t *>(gb + G.keys_b);
-    uint4 *recs_sorted = reinterpret_cast<uint4 *>(gb + G.recs_b);
-    rc = gather_sort(p.gather_keys, keys_sorted, p.gather_recs, recs_sorted, stored, key_bits, gb + G.temp, G.temp_bytes, s);
-    if (rc != RF_OK) return rc;
-    return dispatch<LaunchGatherRows>(sh_degree, half, keys_sorted, recs_sorted, stored, rays, p.attr_grad, s);
+    if (mode == 0) mode = p.trail ? (p.grid.img_w ? 3 : 4) : 2;
+    if ((mode == 3 || mode == 4) && !p.trail) mode = 2;
+    return dispatch<LaunchBackward>(sh_degree, half, p, mode, s);
 }
 
 int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *settings,

@@ -171,17 +171,9 @@ class Pipeline:
         self._cache = _FoamCache()
         #: reuse the packed foam between calls while the inputs are unchanged
         self.cache_foam = True
-        #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics, 3 block cache, 4 direct row atomics, 5 = 4 with the
-        #: colour rows sorted by cell and summed instead of scattered (rf_launch_opts.backward_mode).  Auto: 3 for
-        #: image-shaped batches, 5 for flat ones (4 when gather_rows is off).
+        #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics, 3 block cache, 4 direct row atomics
+        #: (rf_launch_opts.backward_mode)
         self.backward_mode = 0
-        #: flat batches: give trace_backward the scratch of mode 5 (records of the colour-row gradients, sorted and
-        #: summed; 40 bytes per record + the sort's temporary).  The call then synchronises the stream once.
-        self.gather_rows = True
-        #: records the scratch is sized for; grown to what a call reports when it ran out (the excess of that call went
-        #: through atomics: same gradients, slower)
-        self.gather_capacity = 0
-        self._gather_ws = None
         #: trace_forward records the cell every hop enters so that a trace_backward call on the same
         #: inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).  Costs
         #: trail_steps * 4 bytes per ray of HBM (2.1 GB for a 1080p frame at 256 steps), so:
@@ -192,8 +184,14 @@ class Pipeline:
         #:   True / False      always / never (callers that drive trace_backward by hand, like
         #:                     bench.py, set True).
         self.record_trail = "auto"
-        #: hops recorded per ray; rays that take more are re-scanned past this point
+        #: hops recorded per ray; rays that take more are left to a second launch that walks them again by scanning.
+        #: That launch is as long as its longest ray (hundreds of dependent scans): 130 of 1 M rays of the training-shaped
+        #: batch take 257-269 hops and cost 1.4 ms of an 8 ms backward.  So the capacity follows the data: every
+        #: trace_forward leaves the largest hop count of its batch in pinned host memory (asynchronously, no stream
+        #: synchronisation), and the next one that finds it there sizes its trail for it (trail_steps_limit at most).
         self.trail_steps = 256
+        self.trail_steps_limit = 2048
+        self._hops_probe = None
         #: drop the trail (and its memory) once a trace_backward has replayed it; off by default because
         #: the allocation is reused by the next trace_forward of the same shape (a training loop), and a
         #: second backward over the same forward (tests, linearity checks) may replay it again
@@ -213,7 +211,6 @@ class Pipeline:
         self._cache.clear()
         self._trail = None
         self._order = None
-        self._gather_ws = None
 
     def _wants_trail(self, points, attributes) -> bool:
         """"auto": will a trace_backward follow this forward?  Inside an autograd.Function.forward grad mode is off and
@@ -395,8 +392,27 @@ class Pipeline:
             cached = self._order = {"key": key, "order": order, "refs": (rays_c, start_c)}
         opts.ray_order = cached["order"].data_ptr()
 
+    def _probe_hops(self, hops):
+        """Largest hop count of the batch just traced -> pinned host memory, without waiting for it."""
+        pr = self._hops_probe
+        if pr is None:
+            pr = self._hops_probe = {"host": torch.zeros((), dtype=torch.int32).pin_memory(), "event": None}
+        if pr["event"] is not None and not pr["event"].query():
+            return                      # the previous probe has not landed yet: one in flight is enough
+        pr["host"].copy_(hops.max(), non_blocking=True)
+        pr["event"] = torch.cuda.Event()
+        pr["event"].record()
+
+    def _grow_trail_steps(self):
+        pr = self._hops_probe
+        if pr is not None and pr["event"] is not None and pr["event"].query():
+            longest = int(pr["host"])
+            if longest > int(self.trail_steps):
+                self.trail_steps = min((longest * 9 // 8 + 31) // 32 * 32, int(self.trail_steps_limit))
+
     def _new_trail(self, opts, num_rays, dev):
         slots = int(self._lib.rf_trail_slots(num_rays, opts.image_width, opts.image_height))
+        self._grow_trail_steps()
         cap = max(1, int(self.trail_steps))
         old = self._trail
         if old is not None and old["trail"].shape == (cap, slots) and old["trail"].device == dev:
@@ -479,6 +495,7 @@ class Pipeline:
         _lib.check(rc)
         self._foam_done(opts)
         if trail is not None:
+            self._probe_hops(trail[1])
             foam = (points_c, attributes_c, adjacency_c, offsets_c)
             self._trail = {
                 "key": self._trail_key(foam, rays_c, start_c, quantiles_c, settings),
@@ -610,20 +627,6 @@ class Pipeline:
             opts.trail_hops = tr["hops"].data_ptr()
             opts.trail_cap = tr["cap"]
             opts.trail_slots = tr["slots"]
-        produced = None
-        if self.gather_rows and opts.trail and not opts.image_width and int(self.backward_mode) in (0, 5):
-            cap = int(self.gather_capacity) or max(1 << 16, 32 * num_rays)
-            cap = min(cap, 0x7FFFFFFF)
-            need = int(self._lib.rf_gather_workspace_bytes(cap))
-            ws = self._gather_ws
-            if ws is None or ws.numel() < need or ws.device != dev:
-                ws = self._gather_ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            produced = C.c_uint32(0)
-            opts.gather_workspace = ws.data_ptr()
-            opts.gather_workspace_bytes = ws.numel()
-            opts.gather_capacity = cap
-            opts.gather_count = C.pointer(produced)
-            self.gather_capacity = cap
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_backward(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),
@@ -633,10 +636,6 @@ class Pipeline:
                 _ptr(attr_grad), _ptr(point_error), C.byref(opts), _stream_ptr(dev))
         _lib.check(rc)
         self._foam_done(opts)
-        if produced is not None:
-            self.last_gather_records = int(produced.value)
-            if produced.value > self.gather_capacity:   # ran out: the next call gets room for this many and a margin
-                self.gather_capacity = int(produced.value * 1.25) + 1024
         if self.free_trail_after_backward:
             self._trail = None
 

@@ -146,7 +146,7 @@ def _backward_case(foam_factory, d, seed, image, quantiles, with_error, n_points
     return fm, rays, starts, q, dg, g, err, fwd, ref
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("trail", ["rewalk", "replay", "short"])
 @pytest.mark.parametrize("d,image,quantiles,with_error", [
     (0, True, False, False), (1, False, True, True), (2, True, True, False), (2, False, False, True),
@@ -624,39 +624,38 @@ def test_hip_matches_reference_source_goldens(path):
     check_against_golden(z, fwd, bwd, diff.cpu().numpy(), bench, half)
 
 
-@pytest.mark.parametrize("capacity", [0, 1000, 7])
-def test_gather_backward_of_a_flat_batch(foam_factory, capacity):
-    """Backward mode 5 (the default for flat batches): colour-row gradients appended as records, sorted by cell and summed.
-    capacity 0 = the pipeline's own sizing; 1000 / 7 = far too small on purpose: the records that do not fit go through
-    atomics, the gradients are the same, and the pipeline grows its scratch to what the call reported."""
-    d = 3
-    fm = foam_factory(6000, d, 78)
-    rays, starts = H.random_rays(fm, 30_000, seed=6)
-    g = np.random.default_rng(10).normal(size=(30_000, 4)).astype(np.float32)
+def test_trail_capacity_follows_the_longest_ray(foam_factory):
+    """Rays with more hops than the trail holds are re-walked by a second launch as long as its longest ray; the
+    pipeline therefore sizes the next trail for the longest ray of the batch it just traced (read back asynchronously).
+    The gradients do not depend on where the trail ends."""
+    d = 1
+    fm = foam_factory(6000, d, 81)
+    cam, rays, start = H.camera_setup(fm, 64, 48)
+    g = np.random.default_rng(3).normal(size=rays.shape[:-1] + (4,)).astype(np.float32)
     args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
-    fwd = O.trace_forward(*args, rays, starts)
-    ref = O.trace_backward(*args, rays, starts, fwd["rgba"], g)
+    fwd = O.trace_forward(*args, rays, start)
+    ref = O.trace_backward(*args, rays, start, fwd["rgba"], g)
+    longest = int(fwd["num_intersections"].max())
     p, a, adj, off = H.to_torch_foam(fm, DEV)
-    t = lambda x: torch.from_numpy(x).to(DEV)
+    r = torch.from_numpy(rays).to(DEV)
+    s = torch.full(r.shape[:-1], int(start), dtype=torch.int64).to(torch.uint32).to(DEV)
     pipe = _pipeline(d)
-    assert pipe.gather_rows and pipe.backward_mode == 0
-    pipe.gather_capacity = capacity
-    f = pipe.trace_forward(p, a, adj, off, t(rays), t(starts))
-    out = pipe.trace_backward(p, a, adj, off, t(rays), t(starts), f["rgba"], t(g))
-    assert pipe.last_gather_records > 1000            # lit segments of the batch: the records of this call
-    if capacity:
-        assert pipe.gather_capacity >= pipe.last_gather_records   # grown for the next call
-    for key in ("points_grad", "attr_grad"):
-        ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
-        assert ok and rel < 1e-5, (key, rel, worst)
-    # mode 4 on the same inputs: the same sums in another order
-    pipe4 = _pipeline(d)
-    pipe4.backward_mode = 4
-    f4 = pipe4.trace_forward(p, a, adj, off, t(rays), t(starts))
-    out4 = pipe4.trace_backward(p, a, adj, off, t(rays), t(starts), f4["rgba"], t(g))
-    for key in ("points_grad", "attr_grad"):
-        ok, rel, worst = H.grad_close(out[key].cpu().numpy(), out4[key].cpu().numpy())
-        assert ok and rel < 1e-5, (key, rel, worst)
+    pipe.trail_steps = 4
+    for attempt in range(2):
+        f = pipe.trace_forward(p, a, adj, off, r, s)
+        assert pipe._trail["cap"] == (4 if attempt == 0 else pipe.trail_steps)
+        out = pipe.trace_backward(p, a, adj, off, r, s, f["rgba"], torch.from_numpy(g).to(DEV))
+        torch.cuda.synchronize()
+        for key in ("points_grad", "attr_grad"):
+            ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+            assert ok and rel < 1e-5, (attempt, key, rel, worst)
+    assert longest - 1 <= pipe.trail_steps <= 2 * longest + 32   # hops = scans - 1 at most; grown with a margin
+    pipe.trail_steps_limit = 8
+    pipe.trail_steps = 4
+    pipe.trace_forward(p, a, adj, off, r, s)
+    torch.cuda.synchronize()
+    pipe.trace_forward(p, a, adj, off, r, s)
+    assert pipe.trail_steps == 8                                    # never beyond the limit
 
 
 def test_shuffled_batch_is_traced_in_a_coherent_order(foam_factory):

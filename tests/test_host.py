@@ -44,8 +44,7 @@ def test_struct_layouts_match_header():
     assert _lib.LaunchOpts.foam_prepared.offset == 16 and _lib.LaunchOpts.stats.offset == 32
     assert _lib.LaunchOpts.trail.offset == 40 and _lib.LaunchOpts.trail_cap.offset == 56
     assert _lib.LaunchOpts.ray_order.offset == 64 and _lib.LaunchOpts.visit_marks.offset == 72
-    assert _lib.LaunchOpts.gather_workspace.offset == 80 and _lib.LaunchOpts.gather_capacity.offset == 96
-    assert _lib.LaunchOpts.gather_count.offset == 104 and ctypes.sizeof(_lib.LaunchOpts) == 112
+    assert ctypes.sizeof(_lib.LaunchOpts) == 80
 
 
 def test_host_only_entry_points():
