@@ -616,9 +616,12 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
                 k["valu_insts_per_launch"] = int(c.get("SQ_INSTS_VALU", 0))
                 k["effective_clock_GHz_profiled"] = round(cycles / c["duration_ns"], 3) if c.get("duration_ns") else None
                 if name == "forward_kernel" and walk and c.get("SQ_INSTS_VALU"):
-                    useful = (SCAN_VALU_PER_4_FACES / 4.0 * walk["faces_scanned"] + HOP_VALU_PER_LANE * walk["hops"]) / 64.0
+                    scan = SCAN_VALU_PER_4_FACES / 4.0 * walk["faces_scanned"] / 64.0
+                    useful = scan + HOP_VALU_PER_LANE * walk["hops"] / 64.0
                     k["useful_valu_frac"] = round(useful / c["SQ_INSTS_VALU"], 4)
+                    k["useful_scan_valu_frac"] = round(scan / c["SQ_INSTS_VALU"], 4)   # the face tests alone
                     k["useful_share_of_issue_capacity"] = round(k["useful_valu_frac"] * k["valu_issue_frac"], 4)
+                    k["useful_scan_share_of_issue_capacity"] = round(k["useful_scan_valu_frac"] * k["valu_issue_frac"], 4)
             if c.get("hbm_bytes") is not None and ms > 0:
                 gbps = c["hbm_bytes"] / (ms * 1e-3) / 1e9
                 k["hbm_bytes_per_launch"] = int(c["hbm_bytes"])
@@ -663,6 +666,7 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
         "counters_source": (counters or {}).get("source"),
         "counters_stale": stale,
         "useful_valu_frac": per_kernel.get("forward_kernel", {}).get("useful_valu_frac"),
+        "useful_scan_valu_frac": per_kernel.get("forward_kernel", {}).get("useful_scan_valu_frac"),
         "fp32_frac_of_peak": per_kernel.get("forward_kernel", {}).get("fp32_frac_of_peak"),
         "note": "pointer-chasing walk served from L1/L2: HBM is nowhere near its peak and is not the bound; the "
                 "kernel is VALU-issue bound (DESIGN.md section 4).  achieved/frac come from the committed SQ "

@@ -2,6 +2,7 @@
 # workload, the launcher paths, rocprofv3 kernel stats and the PMC passes behind bench.py's roofline.
 #   bash scripts/gpu_evidence.sh [tests] [bench] [configs] [prof] [pmc]      (no argument = everything)
 # Outputs under gpurun_out/ev/; scripts/update_profiles.py copies what is to be kept into profiles/.
+# PMC passes: SQ+GRBM (two), FETCH_SIZE, WRITE_SIZE, L2 hit/miss, L1->L2 / L2->fabric request counts -- one --pmc run each.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/ev
 mkdir -p $O
@@ -22,6 +23,10 @@ if has configs; then
     (timeout 900 python bench.py --workload $w --steps 10 --warmup 3 2>$O/bench_$w.err | tail -1) > $O/bench_$w.json
   done
   (timeout 600 python bench.py --forward-only --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1) > $O/bench_ns_fwd.json
+  # the training loop's call pattern (train.py:176-180): two depth quantiles per ray with depth gradients
+  (timeout 900 python bench.py --quantiles 2 --steps 10 --warmup 3 2>$O/bench_ns_q2.err | tail -1) > $O/bench_ns_q2.json
+  (timeout 900 python bench.py --workload train-batch --quantiles 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1) > $O/bench_train-batch_q2.json
+  (timeout 900 python bench.py --workload train-batch --sh-degree 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1) > $O/bench_train-batch_sh2.json
 fi
 cd /tmp && export TMPDIR=/tmp
 PMCW="${PMC_WORKLOADS:-north-star}"
@@ -38,7 +43,8 @@ if has pmc; then
     i=0
     for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
              "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE" \
-             "FETCH_SIZE" "WRITE_SIZE" ; do
+             "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" ; do
       i=$((i+1))
           mkdir -p $O/pmc_$w
       timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_$w/p$i -o run -- $BENCH > $O/pmc_$w/p$i.log 2>&1
