@@ -253,3 +253,40 @@ def test_reference_python_callers_import_and_reach_this_boundary(monkeypatch):
         render.TraceRays.apply(pipe, kw["points"].requires_grad_(), kw["attributes"].requires_grad_(),
                                kw["point_adjacency"], kw["point_adjacency_offsets"], kw["rays"],
                                kw["start_point"], None, False)
+
+
+def test_bench_roofline_refuses_counters_of_other_kernel_sources(monkeypatch):
+    """profiles/counters.json carries the sha256 of the kernel sources its PMC passes were taken on;
+    bench.py quotes the counters only when its own sources hash to the same value, and says so otherwise."""
+    import json
+
+    import bench
+    from radfoam_amd import build as hip_build
+
+    committed = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "counters.json")))
+    assert committed["north-star"].get("csrc_sha256"), "counters.json must record the sources it was measured on"
+    walk = {"faces_scanned": 4_945_000_000, "hops": 266_000_000, "cells_scanned": 266_000_000}
+    W = dict(bench.WORKLOADS["north-star"], name="north-star", nq=0)
+
+    monkeypatch.setattr(hip_build, "source_hash", lambda: committed["north-star"]["csrc_sha256"])
+    fresh = bench.build_roofline(W, 1, 4.7, 3.9, 5.0e10, 6.0e10, 1.3e9, 1.0e9, walk)
+    assert fresh["counters_stale"] is False and 0.5 < fresh["frac"] < 1.0 and fresh["bound"] == "valu_issue"
+    assert 0.3 < fresh["useful_scan_valu_frac"] < fresh["useful_valu_frac"] < 1.0
+    assert 0.05 < fresh["fp32_frac_of_peak"] < 0.3 and fresh["traffic"] > 1e9
+
+    monkeypatch.setattr(hip_build, "source_hash", lambda: "0" * 64)
+    stale = bench.build_roofline(W, 1, 4.7, 3.9, 5.0e10, 6.0e10, 1.3e9, 1.0e9, walk)
+    assert stale["counters_stale"] is True and stale["frac"] is None and stale["traffic"] is None
+    assert stale["useful_valu_frac"] is None and stale["fp32_frac_of_peak"] is not None   # live figures stay
+    assert stale["kernels"]["forward_kernel"]["avg_launch_ms"] == 4.7
+
+
+def test_the_committed_counters_describe_the_committed_kernel_sources():
+    """The driver runs bench.py on the committed tree: its roofline must not come back stale."""
+    import json
+
+    from radfoam_amd import build as hip_build
+
+    committed = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "counters.json")))
+    assert committed["north-star"]["csrc_sha256"] == hip_build.source_hash(), \
+        "kernel sources changed after the last PMC passes: re-run scripts/gpu_evidence.sh pmc + update_profiles.py"
