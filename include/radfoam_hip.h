@@ -222,6 +222,13 @@ int rf_pack_attributes_backward(int sh_degree, uint32_t num_points, const float 
 int rf_nearest_point(const float *points, uint32_t num_points, const float *queries,
                      uint32_t num_queries, uint32_t *indices, void *scratch, void *stream);
 
+/* radfoam.nn through the tree (torch_bindings/triangulation_bindings.cpp:142-181 over nn_kernel, src/aabb_tree/
+ * aabb_tree.cu:343-415): `points` in kd-order, `aabb_tree` the float[pow2_round_up(num_points)][2][3] boxes of
+ * rf_build_aabb_tree (or the reference's build_aabb_tree) over those points.  Same result as rf_nearest_point -- exact,
+ * lowest index among exact ties -- in O(log num_points) boxes per query: the choice for many queries. */
+int rf_nearest_point_tree(const float *points, uint32_t num_points, const float *aabb_tree, const float *queries,
+                          uint32_t num_queries, uint32_t *indices, void *stream);
+
 /* radfoam.farthest_neighbor, src/delaunay/triangulation_ops.cu:9-44: per point the first farthest
  * Delaunay neighbour (0xFFFFFFFF if none) and the mean half-distance to its neighbours. */
 int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_t *point_adjacency,

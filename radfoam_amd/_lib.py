@@ -80,6 +80,7 @@ SYMBOLS = {
     "rf_pack_attributes": (_INT, [_INT, _INT, _U32, _P, _P, _P, C.c_float, _P, _P]),
     "rf_pack_attributes_backward": (_INT, [_INT, _U32, _P, C.c_float, _P, _P, _P, _P, _P]),
     "rf_nearest_point": (_INT, [_P, _U32, _P, _U32, _P, _P, _P]),
+    "rf_nearest_point_tree": (_INT, [_P, _U32, _P, _P, _U32, _P, _P]),
     "rf_farthest_neighbor": (_INT, [_P, _U32, _P, _P, _P, _P, _P]),
     "rf_ray_order_workspace_bytes": (C.c_size_t, [_U32]),
     "rf_build_ray_order": (_INT, [_P, _P, _U32, _P, _P, C.c_size_t, _P]),

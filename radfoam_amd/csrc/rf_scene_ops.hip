@@ -144,6 +144,74 @@ __global__ __launch_bounds__(256) void nearest_point_finish_kernel(const unsigne
     if (q < num_queries) indices[q] = (uint32_t)(best[q] & 0xFFFFFFFFull);
 }
 
+// ---- nearest point through the AABB tree ---------------------------------------------------------------
+// radfoam.nn as the reference answers it (nn_kernel, src/aabb_tree/aabb_tree.cu:343-415 over aabb_tree.cuh:154-276:
+// a warp of 32 per query, k candidates kept by a warp merge sort, ballot-driven stack).  Here k = 1 is all the callers
+// ask for (the entry cell of a ray origin), so a LANE takes a query and walks the implicit tree depth first, nearer
+// child first, with its stack in private memory: O(log N) boxes per query instead of the N points of the brute-force
+// kernel above, which stays the choice for a handful of camera positions.  Same answer as that kernel, bit for bit:
+// the point distance is the same expression, (distance, index) pairs are compared as one 64-bit key (lowest index among
+// exact ties), and a box is skipped only when its distance is strictly larger than the best so far -- fp32 rounding is
+// monotone through the subtraction, the squares and the fused sums, so a box's distance never exceeds that of a point
+// inside it.  Tree layout (build_aabb_tree, aabb_tree.cu:192-292): P = pow2_round_up(N) nodes of {min[3], max[3]};
+// level d (2^d nodes) starts at node P - 2^(d+1); the deepest level pairs the points (2k, 2k+1).
+__device__ __forceinline__ float box_distance2(const float *__restrict__ node, float qx, float qy, float qz) {
+    const float dx = __builtin_fmaxf(__builtin_fmaxf(node[0] - qx, qx - node[3]), 0.0f);
+    const float dy = __builtin_fmaxf(__builtin_fmaxf(node[1] - qy, qy - node[4]), 0.0f);
+    const float dz = __builtin_fmaxf(__builtin_fmaxf(node[2] - qz, qz - node[5]), 0.0f);
+    return dot3(dx, dy, dz, dx, dy, dz);
+}
+
+__global__ __launch_bounds__(256) void nearest_point_tree_kernel(const float *__restrict__ points, uint32_t num_points,
+                                                                 const float *__restrict__ tree, uint32_t pow2,
+                                                                 uint32_t depth, const float *__restrict__ queries,
+                                                                 uint32_t num_queries, uint32_t *__restrict__ indices) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= num_queries) return;
+    const float qx = queries[3 * (size_t)q], qy = queries[3 * (size_t)q + 1], qz = queries[3 * (size_t)q + 2];
+    unsigned long long best = ~0ull;          // distance bits << 32 | index
+    float best_d2 = __builtin_inff();
+    auto try_point = [&](uint32_t i) {
+        if (i >= num_points) return;
+        const float dx = points[3 * (size_t)i] - qx, dy = points[3 * (size_t)i + 1] - qy, dz = points[3 * (size_t)i + 2] - qz;
+        const float d2 = dot3(dx, dy, dz, dx, dy, dz);
+        if (d2 == d2) {
+            const unsigned long long k = ((unsigned long long)f2bits(d2) << 32) | (unsigned long long)i;
+            if (k < best) {
+                best = k;
+                best_d2 = d2;
+            }
+        }
+    };
+    if (depth == 0) {   // one point
+        try_point(0u);
+        indices[q] = (uint32_t)(best & 0xFFFFFFFFull);
+        return;
+    }
+    uint32_t stack[32];                       // (level << 26) | node of that level; level < 32, node < 2^26
+    int sp = 0;
+    stack[sp++] = 0u;                         // the root: level 0, node 0
+    while (sp > 0) {
+        const uint32_t e = stack[--sp];
+        const uint32_t d = e >> 26, k = e & 0x03FFFFFFu;
+        const float *node = tree + 6 * (size_t)(pow2 - (2u << d) + k);
+        if (box_distance2(node, qx, qy, qz) > best_d2) continue;   // (a NaN query compares false: it visits everything)
+        if (d + 1u == depth) {                // the deepest level: its two points
+            try_point(2u * k);
+            try_point(2u * k + 1u);
+            continue;
+        }
+        const uint32_t c = 2u * k;
+        const float *lo = tree + 6 * (size_t)(pow2 - (4u << d) + c);
+        const float d0 = box_distance2(lo, qx, qy, qz), d1 = box_distance2(lo + 6, qx, qy, qz);
+        const uint32_t near = d1 < d0 ? c + 1u : c, far = d1 < d0 ? c : c + 1u;
+        const float dn = d1 < d0 ? d1 : d0, df = d1 < d0 ? d0 : d1;
+        if (!(df > best_d2)) stack[sp++] = ((d + 1u) << 26) | far;
+        if (!(dn > best_d2)) stack[sp++] = ((d + 1u) << 26) | near;
+    }
+    indices[q] = (uint32_t)(best & 0xFFFFFFFFull);
+}
+
 // ---- farthest neighbour -----------------------------------------------------------------------------
 // reference: farthest_neighbor_kernel, triangulation_ops.cu:9-44 -- the first strict maximum of the
 // neighbour distances (UINT32_MAX when there is none), and the mean half-distance; the reference's
@@ -243,6 +311,25 @@ int rf_nearest_point(const float *points, uint32_t num_points, const float *quer
     hipLaunchKernelGGL(nearest_point_finish_kernel, dim3((num_queries + 255u) / 256u), dim3(256), 0, s, best,
                        num_queries, indices);
     return check_launch("rf_nearest_point");
+}
+
+int rf_nearest_point_tree(const float *points, uint32_t num_points, const float *aabb_tree, const float *queries,
+                          uint32_t num_queries, uint32_t *indices, void *stream) {
+    g_err[0] = 0;
+    if (num_queries == 0) return RF_OK;
+    if (num_points == 0) return fail(RF_ERR_INVALID_ARGUMENT, "rf_nearest_point_tree: no points");
+    if (num_points > (1u << 26)) return fail(RF_ERR_INVALID_ARGUMENT, "rf_nearest_point_tree: more than 2^26 points");
+    if (!points || !aabb_tree || !queries || !indices)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_nearest_point_tree: null pointer");
+    uint32_t pow2 = 1, depth = 0;
+    while (pow2 < num_points) {
+        pow2 <<= 1;
+        ++depth;
+    }
+    hipLaunchKernelGGL(nearest_point_tree_kernel, dim3((num_queries + 255u) / 256u), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), points, num_points, aabb_tree, pow2, depth, queries, num_queries,
+                       indices);
+    return check_launch("rf_nearest_point_tree");
 }
 
 int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_t *point_adjacency,

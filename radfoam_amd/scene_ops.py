@@ -107,6 +107,26 @@ def nearest_point(points: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
     return out.view(torch.uint32).reshape(queries.shape[:-1])
 
 
+def nearest_point_tree(points: torch.Tensor, tree: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
+    """The same answer as ``nearest_point`` through the AABB tree of the (kd-ordered) points: O(log N) boxes per
+    query, a lane per query (rf_nearest_point_tree; reference: nn_kernel, src/aabb_tree/aabb_tree.cu:343-415)."""
+    _check_f32_cuda("points", points)
+    _check_f32_cuda("queries", queries)
+    _check_f32_cuda("aabb_tree", tree)
+    if points.dim() != 2 or points.size(-1) != 3 or queries.size(-1) != 3:
+        raise RuntimeError("points must be [N,3] and queries [...,3]")
+    n = points.size(0)
+    pow2 = 1 if n <= 1 else 1 << ((n - 1).bit_length())
+    if tuple(tree.shape) != (pow2, 2, 3):
+        raise RuntimeError("aabb_tree must have shape [pow2_round_up(num_points), 2, 3]")
+    p, q, t = points.detach().contiguous(), queries.detach().reshape(-1, 3).contiguous(), tree.detach().contiguous()
+    out = torch.empty(q.size(0), dtype=torch.int32, device=p.device)
+    with torch.cuda.device(p.device):
+        rc = _lib.load().rf_nearest_point_tree(_ptr(p), n, _ptr(t), _ptr(q), q.size(0), _ptr(out), _stream(p.device))
+    _lib.check(rc)
+    return out.view(torch.uint32).reshape(queries.shape[:-1])
+
+
 def farthest_neighbor(points: torch.Tensor, point_adjacency: torch.Tensor,
                       point_adjacency_offsets: torch.Tensor):
     """(uint32 index of the farthest Delaunay neighbour, fp32 mean half-distance to the neighbours)."""

@@ -146,14 +146,25 @@ def build_aabb_tree(points: torch.Tensor) -> torch.Tensor:
 
 def nn(points: torch.Tensor, tree: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
     """Index of the nearest point for every query (exact), uint32, shape queries.shape[:-1].
-    float32 CUDA tensors go to the HIP kernel (scene_ops.nearest_point); CPU tensors, which the
-    reference also serves (nn_cpu, aabb_tree.cu:417-478), to the torch restatement below."""
-    del tree
+    float32 CUDA tensors go to the HIP kernels -- a brute-force pass for a handful of queries, the tree walk
+    (scene_ops.nearest_point_tree over the caller's ``tree`` of the kd-ordered points) for many, same answer --; CPU
+    tensors, which the reference also serves (nn_cpu, aabb_tree.cu:417-478), to the torch restatement below."""
     if points.dtype != queries.dtype:
         raise RuntimeError("points and queries must have the same dtype")
     if points.is_cuda and points.dtype == torch.float32:
         from . import scene_ops
-        return scene_ops.nearest_point(points, queries.to(points.device)).to(queries.device)
+        q = queries.to(points.device)
+        n = points.size(0)
+        # Camera positions (up to a few thousand): one streaming pass over the points per query, exact whatever the
+        # state of `tree` -- RadFoamScene keeps the tree of its last triangulation update while the optimiser moves the
+        # points, and a walk through stale boxes may miss the true nearest point.  Bulk queries (per-ray origins, test
+        # sets): the walk through the caller's tree, the reference's own route (aabb_tree.cu:343-415); the tree must
+        # describe these points, as the reference requires.
+        many = q.numel() // 3 > 4096
+        if many and isinstance(tree, torch.Tensor) and tree.is_cuda and tree.dtype == torch.float32 \
+                and tuple(tree.shape) == (_foam.pow2_round_up(n), 2, 3):
+            return scene_ops.nearest_point_tree(points, tree, q).to(queries.device)
+        return scene_ops.nearest_point(points, q).to(queries.device)
     q = queries.reshape(-1, 3).to(points.device)
     out = torch.empty(q.size(0), dtype=torch.int64, device=points.device)
     p = points.detach().double()

@@ -184,6 +184,35 @@ def test_nearest_point_matches_checker():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 33, 1000, 200_000])
+def test_nearest_point_through_the_tree_equals_the_brute_force_search(n):
+    """radfoam.nn with many queries walks the caller's AABB tree (the reference's route, aabb_tree.cu:343-415), a lane per
+    query; the answer is the brute-force kernel's, index for index -- queries inside the cloud, far outside it, on
+    points, and duplicated points (lowest index wins)."""
+    import radfoam
+    from radfoam_amd import scene_ops
+    rng = np.random.default_rng(40 + n)
+    p = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    if n >= 33:
+        p[7] = p[21]                                  # an exact tie
+    p = np.ascontiguousarray(p[foam.kd_order(p)])     # the tree is over kd-ordered points
+    q = np.concatenate([rng.uniform(-1, 1, (4000, 3)), rng.normal(0, 30, (500, 3)), p[rng.integers(0, n, 300)],
+                        [[1e30, 0, 0], [0, -1e-30, 0]]]).astype(np.float32)
+    pc, qc = _cuda(p), _cuda(q)
+    tree = radfoam.build_aabb_tree(pc)
+    brute = scene_ops.nearest_point(pc, qc)
+    walked = scene_ops.nearest_point_tree(pc, tree, qc)
+    assert walked.dtype == torch.uint32 and torch.equal(walked.view(torch.int32), brute.view(torch.int32))
+    assert torch.equal(radfoam.nn(pc, tree, qc).view(torch.int32), brute.view(torch.int32))     # > 4096 queries: the tree
+    assert torch.equal(radfoam.nn(pc, tree, qc[:5]).view(torch.int32), brute[:5].view(torch.int32))
+    if n == 1000:
+        want = R.nearest_point(p, q[:200])
+        np.testing.assert_array_equal(walked[:200].cpu().numpy(), want)
+    with pytest.raises(RuntimeError, match="aabb_tree must have shape"):
+        scene_ops.nearest_point_tree(pc, tree[:1].repeat(3, 1, 1), qc)
+
+
+@pytest.mark.gpu
 def test_nearest_point_ties_take_the_lowest_index():
     import radfoam
     p = np.zeros((5000, 3), dtype=np.float32)
