@@ -24,9 +24,9 @@
 //              cell's face list, cell record and SH row can then all be requested at once.
 //   nbr[e]     adj[e] again (kNone for padding entries), 4 B: what the geometry-only repack streams instead of
 //              the 12-B links when only the points moved (an optimiser step between two triangulation rebuilds)
-//   SH rows    the 3B colour coefficients of a cell, 16-B aligned rows of sh_stride scalars;
-//              present only when the caller's row pitch (A scalars) is not 16-B aligned
-//              (d=1,3); otherwise the kernels read the caller's attribute rows in place.
+//   SH rows    the 3B colour coefficients of a cell, aligned rows of sh_stride scalars; present only for fp16
+//              attributes whose row pitch (A scalars) is odd (d=1,3); otherwise the kernels read the caller's
+//              attribute rows in place (fp32 rows of odd pitch through unaligned 16-byte loads).
 #pragma once
 
 #include <stddef.h>
@@ -67,9 +67,12 @@ inline FoamLayout foam_layout(uint32_t num_points, uint32_t adj_size, int sh_deg
     FoamLayout L{};
     const uint32_t A = attribute_dim(sh_degree);
     const uint32_t ncoef = A - 1;
-    // rows readable in place iff the pitch keeps every row aligned for the vector loads used:
-    // fp32 rows are read as float4 (16 B), fp16 rows as 4 halves (8 B)
-    const bool in_place = (A % 4u) == 0u;
+    // fp32 rows are read in place whatever their pitch: as float4 (16 B) from addresses that are only 4-byte aligned
+    // when A is odd (d = 1, 3), which the hardware serves in its unaligned access mode at no measurable cost
+    // (profiles/r03/p_sh_rows_in_place_*: the 4 M-point SH-3 frame 20.5 -> 20.3 ms) -- round 2 repacked those rows
+    // into aligned ones in every step (0.24 ms for 2 M points, 0.45 ms for 4 M).  fp16 rows are read as 4 halves
+    // (8 B); with an odd pitch they are only 2-byte aligned, which dword loads do not accept: repacked.
+    const bool in_place = (A % 4u) == 0u || !attr_half;
     L.sh_repacked = !in_place;
     L.sh_stride = in_place ? A : (uint32_t)align_up(ncoef, 4);
     L.cells_off = 0;

@@ -25,7 +25,7 @@
 //   prepare_foam_kernel    prefetch_adjacent_diff_kernel :546-568  (+ cell/face/link packing)
 //   prepare_geometry_kernel  the same, points-dependent part only (adjacency unchanged)
 //   adjacent_diff_kernel   prefetch_adjacent_diff_kernel :546-568  (plain half4 table)
-//   repack_sh_kernel       (no counterpart: aligned SH rows)
+//   repack_sh_kernel       (no counterpart: aligned SH rows for fp16 attributes of odd pitch)
 //   forward_kernel         forward :14-130 and benchmark :472-544
 //   backward_kernel        backward :132-343 (re-walk); backward_replay_kernel (modes 1, 2),
 //                          backward_replay_cached_kernel (mode 3, image-shaped batches) and
