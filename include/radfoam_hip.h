@@ -90,6 +90,11 @@ typedef struct rf_launch_opts {
     /* any ray scans cell i (the caller zeroes it).  Feeds the compulsory-traffic floor of bench.py's   */
     /* roofline: bytes of the distinct cells, face lists and colour rows a frame touches at least once. */
     uint8_t *visit_marks;
+    uint32_t forward_mode;    /* rf_trace_forward only: 0 = auto, 1 = the face scan requests a cell's blocks one */
+                              /*   at a time (six waves per SIMD hide the latency: large image launches), 2 = the */
+                              /*   first six blocks are requested together at the hop that enters the cell (four  */
+                              /*   waves per SIMD: flat batches, launches of at most 1024 blocks).  Same results  */
+                              /*   bit for bit; auto picks by launch shape.                                       */
 } rf_launch_opts;
 
 /* Last error message of the calling thread ("" if none). */

@@ -57,6 +57,7 @@ class LaunchOpts(C.Structure):
         ("trail_slots", C.c_uint32),
         ("ray_order", C.c_void_p),
         ("visit_marks", C.c_void_p),
+        ("forward_mode", C.c_uint32),
     ]
 
 

@@ -35,7 +35,6 @@
 
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 
 #include "../../include/radfoam_hip.h"
@@ -150,6 +149,9 @@ inline __host__ __device__ uint32_t tile_chunk(const RayGrid &g) {
     }
     return 16u;
 }
+
+constexpr uint32_t kResidentBlocks = 1024;   // 256 CUs x 4 blocks: a launch of the eager forward (4 waves per SIMD) that is resident at once
+constexpr int kEagerBlocks = 6;
 
 // blocks to launch: whole rounds of 8 chunks
 inline uint32_t launch_blocks(const RayGrid &g) {
@@ -313,6 +315,54 @@ __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t c
     return r;
 }
 
+// The first K blocks of a cell's face list, all requested at once (a cell has 18.6 faces on average: K = 6 holds the
+// whole list of most cells); lists shorter than K blocks re-request their last block (an L1 hit, not used).
+template <int K>
+struct GeoBlocks {
+    GeoXY A[K > 0 ? K : 1];
+    GeoZ B[K > 0 ? K : 1];
+};
+
+template <int K>
+__device__ __forceinline__ void load_geo_blocks(const uint16_t *geo, uint32_t first, uint32_t cnt, GeoBlocks<K> &G) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(geo + (size_t)first * 3u);
+    const uint32_t last = cnt ? (cnt >> 2) - 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < K; ++i) load_geo_block(src + 6u * (last < (uint32_t)i ? last : (uint32_t)i), G.A[i], G.B[i]);
+}
+
+// scan_faces with the first K blocks already in registers (or on their way); same arithmetic in the same order
+template <int K>
+__device__ __forceinline__ ScanResult scan_faces_eager(const GeoBlocks<K> &G, const uint16_t *blk, uint32_t cnt, float Px,
+                                                       float Py, float Pz, float Ox, float Oy, float Oz, float dx,
+                                                       float dy, float dz) {
+    ScanResult r;
+    constexpr int kUnset = -0x40000000;
+    ScanState S;
+    S.rel = kUnset;
+    S.best = {1.0f, __builtin_inff()};
+    const float cx = Px - Ox, cy = Py - Oy, cz = Pz - Oz;
+    const v2f C2x = {cx, cx}, C2y = {cy, cy}, C2z = {cz, cz};
+    const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        if ((uint32_t)(4 * i) < cnt) scan_block(S, G.A[i], G.B[i], C2x, C2y, C2z, d2x, d2y, d2z);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(blk) + 6 * K;
+    for (uint32_t k = 4u * K; k < cnt; k += 4) {
+        GeoXY A;
+        GeoZ B;
+        load_geo_block(src, A, B);
+        src += 6;
+        scan_block(S, A, B, C2x, C2y, C2z, d2x, d2y, d2z);
+    }
+    const int rel = S.rel;
+    const v2f best = S.best;
+    const bool found = rel > kUnset / 2;
+    r.k = found ? (cnt - 4u) + (uint32_t)rel : kNone;
+    r.t1 = found ? best.y / best.x : __builtin_inff();
+    return r;
+}
+
 // fp16-rounded offset from cell p to its neighbour q, as the face tables hold it (pack_diff)
 __device__ __forceinline__ void face_offset(const float4 &p, const float4 &q, float &ox, float &oy, float &oz) {
     ox = (float)(_Float16)(q.x - p.x);
@@ -436,13 +486,20 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 #ifndef RF_FWD_WAVES_D3
 #define RF_FWD_WAVES_D3 5
 #endif
-constexpr int forward_waves(int deg, bool quant, bool stats) {
+// EAGER instances (the first kEagerBlocks face blocks of a cell requested at once, at the hop that enters it): 122 VGPRs
+// without spills at 4 waves per SIMD up to SH degree 2; 3 waves for degree 3 and with quantile code (measured on the
+// training batch: degree 3 forward 4.94 ms at 4 waves, 4.64 at 3; with quantiles 7.66 -- spills -- and 4.62).
+#ifndef RF_FWD_WAVES_EAGER
+#define RF_FWD_WAVES_EAGER 4
+#endif
+constexpr int forward_waves(int deg, bool quant, bool stats, bool eager) {
+    if (eager) return (deg <= 2 && !quant) ? RF_FWD_WAVES_EAGER : 3;
     if (quant || stats) return RF_FWD_WAVES_OTHER;
     return deg <= 2 ? RF_FWD_WAVES_MAIN : RF_FWD_WAVES_D3;
 }
 
-template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS>
-__global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forward_kernel(FwdParams p) {
+template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS, bool EAGER>
+__global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS, EAGER)) void forward_kernel(FwdParams p) {
     const uint32_t lane = threadIdx.x & 63u;
 #ifdef RF_EXPERIMENT_TIMELINE
     const unsigned long long tl_start = wall_clock64();
@@ -509,6 +566,8 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
         cnt = fv.poff[cur + 1] - nb;
         head = fv.cells[cur];
     }
+    GeoBlocks<EAGER ? kEagerBlocks : 0> GB;
+    if constexpr (EAGER) load_geo_blocks(fv.geo, nb, cnt, GB);
     uint32_t wave_steps = 0;
     uint32_t hops = 0;
     while (ballot(alive) != 0ull) {
@@ -521,7 +580,10 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
         sr.t1 = __builtin_inff();
         sr.k = kNone;
         if (alive) {
-            sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
+            if constexpr (EAGER)
+                sr = scan_faces_eager(GB, fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
+            else
+                sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
             if (want_stats) {
                 st_cells++;
                 st_faces += fv.offsets[cur + 1] - fv.offsets[cur];
@@ -537,6 +599,7 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS)) void forw
             nnb = link.first;
             ncnt = link.count;
             nhead = fv.cells[nxt];
+            if constexpr (EAGER) load_geo_blocks(fv.geo, nnb, ncnt, GB);
             if constexpr (!BENCH) {
                 // trail: the cell each hop enters, for trace_backward to replay
                 if (p.trail) {
@@ -1192,9 +1255,6 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 #ifndef RF_DTABLE_ROWS
 #define RF_DTABLE_ROWS 768
 #endif
-#ifndef RF_DTABLE_EPOCH
-#define RF_DTABLE_EPOCH 4
-#endif
 #ifndef RF_STAGE_LANES_D3
 #define RF_STAGE_LANES_D3 32
 #endif
@@ -1300,6 +1360,9 @@ struct TrailWalker {
     uint32_t cur, hops, recorded, i, n, id0, id1, slot;
     size_t slots;
     bool alive;
+#ifdef RF_EXPERIMENT_SECTIONS
+    unsigned long long sec_wait = 0, sec_segment = 0;   // wave clocks: until the hop's records are there / in backward_segment
+#endif
 
     __device__ __forceinline__ void init(const BwdParams &p) {
         uint32_t ray;
@@ -1333,6 +1396,9 @@ struct TrailWalker {
     // one hop of every live lane; G receives the gradients of the segment just crossed (if any)
     __device__ __forceinline__ void step(const BwdParams &p, StepGrad &G) {
         const FoamView &fv = p.foam;
+#ifdef RF_EXPERIMENT_SECTIONS
+        const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
         if (alive) {
             n++;
             if (n > p.settings.max_intersections) alive = false;
@@ -1354,15 +1420,26 @@ struct TrailWalker {
             face_offset(head, nhead, ox, oy, oz);
             face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
         }
+#ifdef RF_EXPERIMENT_SECTIONS
+        asm volatile("" : "+v"(t1));
+        const unsigned long long c1 = __builtin_readcyclecounter();
+        sec_wait += c1 - c0;
+#endif
         if (alive) {
             if (t1 > R.t0) {
                 if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
             }
+#ifdef RF_EXPERIMENT_SECTIONS
+            asm volatile("" : "+v"(G.dL_ds));
+#endif
             R.t0 = __builtin_fmaxf(R.t0, t1);
             cur = id0;
             head = nhead;
             i++;
         }
+#ifdef RF_EXPERIMENT_SECTIONS
+        sec_segment += __builtin_readcyclecounter() - c1;
+#endif
         id0 = id1;
         id1 = id2;
         q0 = q1;
@@ -1548,8 +1625,16 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
 
     StepGrad G;
     clear_step(G);
+#ifdef RF_EXPERIMENT_SECTIONS
+    unsigned long long sec_tables = 0, sec_rows = 0, sec_steps = 0, sec_total = __builtin_readcyclecounter();
+#endif
     while (ballot(W.alive) != 0ull) {
         W.step(p, G);
+#ifdef RF_EXPERIMENT_SECTIONS
+        sec_steps++;
+        const unsigned long long e0 = __builtin_readcyclecounter();
+        unsigned long long e1 = e0;
+#endif
 
         if (ballot(G.has) != 0ull) {
             // density gradient: lanes of the wave in the same cell merged (DPP xor stages), then into the block's table
@@ -1577,6 +1662,9 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                     if (pv[2] != 0.0f) table_add<DROWS>(s_tab[3], G.prev, pv[2], p.points_grad + 2, (size_t)3);
                 }
             }
+#ifdef RF_EXPERIMENT_SECTIONS
+            e1 = __builtin_readcyclecounter();
+#endif
             // colour rows: stage lane-major, emit column-major (two rows per pass, a lane per column)
             const bool lit = G.has && G.row;
             if (ballot(lit) != 0ull) {
@@ -1643,7 +1731,24 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
         G.has = false;
         G.row = false;
         G.pg_on = false;
+#ifdef RF_EXPERIMENT_SECTIONS
+        sec_tables += e1 - e0;
+        sec_rows += __builtin_readcyclecounter() - e1;
+#endif
     }
+#ifdef RF_EXPERIMENT_SECTIONS
+    // wave clocks per section: [8] waiting for the hop's records + face hit, [9] backward_segment (colour row gather and
+    // the segment's arithmetic), [10] density / point-gradient tables, [11] colour rows staged and sent, [12] the whole
+    // walk, [13] wave-steps
+    if (p.stats && lane == 0u) {
+        atomicAdd(p.stats + 8, W.sec_wait);
+        atomicAdd(p.stats + 9, W.sec_segment);
+        atomicAdd(p.stats + 10, sec_tables);
+        atomicAdd(p.stats + 11, sec_rows);
+        atomicAdd(p.stats + 12, (unsigned long long)__builtin_readcyclecounter() - sec_total);
+        atomicAdd(p.stats + 13, sec_steps);
+    }
+#endif
     // every wave of the block is done: what the tables still hold goes to memory
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < (uint32_t)(4 * DROWS); e += kBlock) {
@@ -1983,18 +2088,25 @@ static int dispatch(int sh_degree, bool half, Args &&...args) {
 
 template <int DEG, bool HALF>
 struct LaunchForward {
-    static int run(const FwdParams &p, bool bench, hipStream_t stream) {
+    static int run(const FwdParams &p, bool bench, uint32_t forward_mode, hipStream_t stream) {
         uint32_t nb = launch_blocks(p.grid);
         if (nb == 0) return RF_OK;
-        size_t lds = 0;
+        // Eager face blocks where a launch waits on memory rather than on issue slots: a flat batch (its lanes share
+        // little, most face lists come from HBM) and any launch small enough to be resident at once with at most four
+        // waves per SIMD (the launch is as long as its longest ray's chain of dependent loads).
+        const bool eager = forward_mode ? forward_mode == 2u : (p.grid.img_w == 0 || nb <= kResidentBlocks);
         if (bench)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false>), dim3(nb), dim3(kBlock), lds, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
         else if (p.stats)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, true>), dim3(nb), dim3(kBlock), lds, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, true, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+        else if (p.nq && eager)
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, true>), dim3(nb), dim3(kBlock), 0, stream, p);
         else if (p.nq)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false>), dim3(nb), dim3(kBlock), lds, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+        else if (eager)
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, true>), dim3(nb), dim3(kBlock), 0, stream, p);
         else
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false>), dim3(nb), dim3(kBlock), lds, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
         return check_launch(bench ? "rf_trace_benchmark" : "rf_trace_forward");
     }
 };
@@ -2130,6 +2242,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_depths || !quantile_point_indices))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: depth quantile buffers missing");
+    if (opts->forward_mode > 2u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: forward_mode must be 0..2");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -2165,7 +2278,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
         p.trail_cap = opts->trail_cap;
         p.trail_slots = opts->trail_slots;
     }
-    return dispatch<LaunchForward>(sh_degree, half, p, false, s);
+    return dispatch<LaunchForward>(sh_degree, half, p, false, opts->forward_mode, s);
 }
 
 int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *settings,
@@ -2272,7 +2385,7 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
     p.cam = *camera;
     p.inv_tan_half_fov = 1.0f / tanf(camera->fov * 0.5f);
     p.rgba8 = ray_rgba;
-    return dispatch<LaunchForward>(sh_degree, half, p, true, s);
+    return dispatch<LaunchForward>(sh_degree, half, p, true, 1u, s);
 }
 
 }  // extern "C"

@@ -174,6 +174,11 @@ class Pipeline:
         #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics, 3 block cache, 4 direct row atomics
         #: (rf_launch_opts.backward_mode)
         self.backward_mode = 0
+        #: 0 auto, 1 face blocks requested one at a time, 2 the first six of a cell together (rf_launch_opts.forward_mode;
+        #: same results, auto picks by launch shape)
+        self.forward_mode = 0
+        #: experiment builds only (scripts/): int64 device tensor handed to rf_trace_backward as rf_launch_opts.stats
+        self.experiment_stats = None
         #: trace_forward records the cell every hop enters so that a trace_backward call on the same
         #: inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).  Costs
         #: trail_steps * 4 bytes per ray of HBM (2.1 GB for a 1080p frame at 256 steps), so:
@@ -315,6 +320,7 @@ class Pipeline:
         opts.workspace_bytes = ws.numel()
         opts.foam_prepared = 1 if hit else (2 if topo else 0)
         opts.backward_mode = int(self.backward_mode)
+        opts.forward_mode = int(self.forward_mode)
         # rays given as an image [H, W, 6]: let a wave own an 8x8 pixel tile (a degenerate "image" such
         # as [B, 1, 6] is a flat batch: tiles of it would be mostly empty)
         if len(rays_shape) == 3 and rays_shape[0] >= 16 and rays_shape[1] >= 16:
@@ -627,6 +633,8 @@ class Pipeline:
             opts.trail_hops = tr["hops"].data_ptr()
             opts.trail_cap = tr["cap"]
             opts.trail_slots = tr["slots"]
+        if self.experiment_stats is not None:
+            opts.stats = self.experiment_stats.data_ptr()
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_backward(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),

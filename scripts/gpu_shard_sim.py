@@ -26,6 +26,8 @@ ap.add_argument("--points", type=int, default=2_000_000)
 ap.add_argument("--seed", type=int, default=5)
 ap.add_argument("--sh-degree", type=int, default=2)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--worlds", type=int, nargs="+", default=[1, 2, 4, 8])
+ap.add_argument("--cuts", nargs="+", default=["balanced", "even"])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 d = args.sh_degree
@@ -64,8 +66,8 @@ row_cost = full["num_intersections"].reshape(1080, -1).to(torch.int64).view(1080
 ex = rdist.SparseGradExchange()
 pitch = ex._pitch(A)
 out = {"workload": {"num_points": n, "sh_degree": d, "frame": [1080, 1920], "seed": args.seed}, "worlds": {}}
-for world in (1, 2, 4, 8):
-    for cut in (("balanced", "even") if world > 1 else ("even",)):
+for world in args.worlds:
+    for cut in (tuple(args.cuts) if world > 1 else ("even",)):
         bounds = rdist.balanced_row_blocks(row_cost, world, align=8) if cut == "balanced" else \
             [rdist.row_block(1080, r, world)[0] for r in range(world)] + [1080]
         ranks = []

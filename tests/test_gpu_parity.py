@@ -45,21 +45,27 @@ def _run_forward(pipe, fm, rays, start, attr_dtype=None, **kw):
     return {k: v.cpu() for k, v in out.items()}, (p, a, adj, off, r, s)
 
 
+@pytest.mark.parametrize("forward_mode", [1, 2])
 @pytest.mark.parametrize("d", [0, 1, 2, 3])
-def test_forward_image_bit_exact(foam_factory, d):
+def test_forward_image_bit_exact(foam_factory, d, forward_mode):
+    """forward_mode: 1 = face blocks requested one at a time (what large image launches run), 2 = the first six of a
+    cell together (flat batches and small launches: what mode 0 picks for every other test of this file)."""
     fm = foam_factory(6000, d, 11)
     cam, rays, start = H.camera_setup(fm, 96, 64)
     ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
                           fm["point_adjacency_offsets"], rays, start)
-    got, _ = _run_forward(_pipeline(d), fm, rays, start)
+    pipe = _pipeline(d)
+    pipe.forward_mode = forward_mode
+    got, _ = _run_forward(pipe, fm, rays, start)
     assert got["rgba"].shape == (64, 96, 4) and got["num_intersections"].shape == (64, 96, 1)
     np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
     np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), ref["rgba"].view(np.uint32))
     assert ref["rgba"][..., 3].max() > 0.5  # the scene is actually hit
 
 
+@pytest.mark.parametrize("forward_mode", [1, 2])
 @pytest.mark.parametrize("d", [0, 2, 3])
-def test_forward_flat_rays_quantiles_contribution(foam_factory, d):
+def test_forward_flat_rays_quantiles_contribution(foam_factory, d, forward_mode):
     fm = foam_factory(6000, d, 12)
     rays, starts = H.random_rays(fm, 5000, seed=3)
     rng = np.random.default_rng(5)
@@ -67,7 +73,9 @@ def test_forward_flat_rays_quantiles_contribution(foam_factory, d):
     ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
                           fm["point_adjacency_offsets"], rays, starts, depth_quantiles=q,
                           return_contribution=True, num_threads=1)
-    got, _ = _run_forward(_pipeline(d), fm, rays, starts, depth_quantiles=q, return_contribution=True)
+    pipe = _pipeline(d)
+    pipe.forward_mode = forward_mode
+    got, _ = _run_forward(pipe, fm, rays, starts, depth_quantiles=q, return_contribution=True)
     np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
     np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), ref["rgba"].view(np.uint32))
     np.testing.assert_array_equal(got["depth_indices"].numpy().view(np.uint32), ref["depth_indices"])
@@ -79,15 +87,18 @@ def test_forward_flat_rays_quantiles_contribution(foam_factory, d):
     assert abs(float(got["contribution"].double().sum()) - float(got["rgba"][..., 3].double().sum())) < 1e-2
 
 
+@pytest.mark.parametrize("forward_mode", [1, 2])
 @pytest.mark.parametrize("d", [0, 1, 2, 3])
-def test_forward_half_attributes(foam_factory, d):
+def test_forward_half_attributes(foam_factory, d, forward_mode):
     fm = foam_factory(6000, d, 13)
     fm16 = dict(fm)
     fm16["attributes"] = fm["attributes"].astype(np.float16)
     cam, rays, start = H.camera_setup(fm, 64, 48)
     ref = O.trace_forward(d, fm16["points"], fm16["attributes"], fm16["point_adjacency"],
                           fm16["point_adjacency_offsets"], rays, start, return_contribution=True)
-    got, _ = _run_forward(_pipeline(d, torch.float16), fm16, rays, start, return_contribution=True)
+    pipe = _pipeline(d, torch.float16)
+    pipe.forward_mode = forward_mode
+    got, _ = _run_forward(pipe, fm16, rays, start, return_contribution=True)
     assert got["rgba"].dtype == torch.float16 and got["contribution"].dtype == torch.float16
     np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
     np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint16), ref["rgba"].view(np.uint16))
@@ -159,6 +170,7 @@ def test_backward_parity(foam_factory, d, image, quantiles, with_error, mode, tr
     fm, rays, starts, q, dg, g, err, fwd, ref = _backward_case(foam_factory, d, 20 + d, image, quantiles, with_error)
     pipe = _pipeline(d)
     pipe.backward_mode = mode
+    pipe.forward_mode = 1 + mode % 2    # the trail comes from either forward instance (both write the same one)
     p, a, adj, off = H.to_torch_foam(fm, DEV)
     t = lambda x: None if x is None else torch.from_numpy(x).to(DEV)
     tr, ts, tq = t(rays), t(starts), t(q)
@@ -180,6 +192,36 @@ def test_backward_parity(foam_factory, d, image, quantiles, with_error, mode, tr
         ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
         assert ok and rel < 1e-5, (key, rel, worst)
         assert np.abs(ref[key]).max() > 0
+
+
+@pytest.mark.parametrize("width,height", [(96, 40), (70, 24), (33, 8), (64, 72)])
+def test_short_and_ragged_images(foam_factory, width, height):
+    """Frames whose height or width is not a multiple of the 16x16 block (partly empty blocks and waves; (33, 8) is below
+    the 16-row minimum and goes down the flat-batch path): forward bit for bit in both forward modes, gradients by trail
+    replay and by re-walk -- the shapes a frame cut into row blocks over several GPUs produces."""
+    d = 2
+    fm = foam_factory(5000, d, 31)
+    cam, rays, start = H.camera_setup(fm, width, height)
+    starts = np.full(rays.shape[:-1], start, dtype=np.uint32)
+    rng = np.random.default_rng(7)
+    g = rng.normal(size=rays.shape[:-1] + (4,)).astype(np.float32)
+    args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    fwd = O.trace_forward(*args, rays, starts)
+    ref = O.trace_backward(*args, rays, starts, fwd["rgba"], g, num_threads=1)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    t = lambda x: torch.from_numpy(x).to(DEV)
+    for mode, record, forward_mode in ((3, True, 1), (2, False, 2)):
+        pipe = _pipeline(d)
+        pipe.backward_mode = mode
+        pipe.record_trail = record
+        pipe.forward_mode = forward_mode
+        f = pipe.trace_forward(p, a, adj, off, t(rays), t(starts))
+        np.testing.assert_array_equal(f["rgba"].cpu().numpy().view(np.uint32), fwd["rgba"].view(np.uint32))
+        np.testing.assert_array_equal(f["num_intersections"].cpu().numpy().view(np.uint32), fwd["num_intersections"])
+        out = pipe.trace_backward(p, a, adj, off, t(rays), t(starts), f["rgba"], t(g))
+        for key in ("points_grad", "attr_grad"):
+            ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+            assert ok and rel < 1e-5, (mode, key, rel, worst)
 
 
 @pytest.mark.parametrize("mode", [2, 3])

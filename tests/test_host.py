@@ -44,7 +44,8 @@ def test_struct_layouts_match_header():
     assert _lib.LaunchOpts.foam_prepared.offset == 16 and _lib.LaunchOpts.stats.offset == 32
     assert _lib.LaunchOpts.trail.offset == 40 and _lib.LaunchOpts.trail_cap.offset == 56
     assert _lib.LaunchOpts.ray_order.offset == 64 and _lib.LaunchOpts.visit_marks.offset == 72
-    assert ctypes.sizeof(_lib.LaunchOpts) == 80
+    assert _lib.LaunchOpts.forward_mode.offset == 80
+    assert ctypes.sizeof(_lib.LaunchOpts) == 88
 
 
 def test_host_only_entry_points():
