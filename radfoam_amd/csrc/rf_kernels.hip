@@ -26,7 +26,8 @@
 //   prepare_geometry_kernel  the same, points-dependent part only (adjacency unchanged)
 //   adjacent_diff_kernel   prefetch_adjacent_diff_kernel :546-568  (plain half4 table)
 //   repack_sh_kernel       (no counterpart: aligned SH rows for fp16 attributes of odd pitch)
-//   forward_kernel         forward :14-130 and benchmark :472-544
+//   forward_kernel         forward :14-130 and benchmark :472-544 (EAGER instances: the first six face blocks of
+//                          a cell requested at the hop that enters it -- flat batches and small launches)
 //   backward_kernel        backward :132-343 (re-walk); backward_replay_kernel (modes 1, 2),
 //                          backward_replay_cached_kernel (mode 3, image-shaped batches) and
 //                          backward_replay_direct_kernel (mode 4, flat batches): the same functor over
@@ -235,12 +236,12 @@ struct __attribute__((aligned(8))) GeoZ {
 // expanded divides.
 // The winner is tracked relative to the block being scanned (`rel`, inline constants 0..3) and rebased once per
 // iteration, instead of materialising k+j per face.
-// Measured out in round 3 (profiles/r03/c_ab_scan_pipe_*; the code is in commit 488b7a4): requesting the first block of
-// the next cell at hop time, from the link just read (forward 4.75 ms against 4.67), and on top of that software-
-// pipelining the block loop with inline-asm loads and an explicit s_waitcnt -- left to itself the optimiser rotates a
-// source-level pipeline back into load-wait-compute -- (4.83 ms: the six register copies and the address select per
-// iteration cost more issue slots than the exposed L1 latency they hide; the kernel is issue-bound, six waves per SIMD
-// already cover the rest).
+// Measured out for whole frames in round 3 (profiles/r03/c_ab_scan_pipe_*; the code is in commit 488b7a4): requesting
+// the first block of the next cell at hop time, from the link just read (forward 4.75 ms against 4.67), and on top of
+// that software-pipelining the block loop with inline-asm loads and an explicit s_waitcnt -- left to itself the optimiser
+// rotates a source-level pipeline back into load-wait-compute -- (4.83 ms: the six register copies and the address
+// select per iteration cost more issue slots than the exposed L1 latency they hide; a whole frame is issue-bound, six
+// waves per SIMD already cover the rest).  Flat batches and small launches are not: scan_faces_eager below.
 __device__ __forceinline__ void load_geo_block(const uint32_t *src, GeoXY &A, GeoZ &B) {
     A = *reinterpret_cast<const GeoXY *>(src);
     B = *reinterpret_cast<const GeoZ *>(src + 4);
@@ -1471,9 +1472,16 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
     clear_step(G);
     uint32_t it = 0;
     bool block_alive = true;
+#ifdef RF_EXPERIMENT_SECTIONS
+    unsigned long long sec_cache = 0, sec_flush = 0, sec_steps = 0, sec_total = __builtin_readcyclecounter();
+#endif
     while (block_alive) {
         if (ballot(W.alive) != 0ull) {
             W.step(p, G);
+#ifdef RF_EXPERIMENT_SECTIONS
+            sec_steps++;
+            const unsigned long long e0 = __builtin_readcyclecounter();
+#endif
 
             const uint32_t lane = threadIdx.x & 63u;
             if (ballot(G.has) != 0ull) {
@@ -1538,14 +1546,35 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
             G.has = false;
             G.row = false;
             G.pg_on = false;
+#ifdef RF_EXPERIMENT_SECTIONS
+            sec_cache += __builtin_readcyclecounter() - e0;
+#endif
         }
         it++;
         if ((it & (kEpoch - 1u)) == 0u) {
+#ifdef RF_EXPERIMENT_SECTIONS
+            const unsigned long long f0 = __builtin_readcyclecounter();
+#endif
             block_alive = __syncthreads_or(W.alive ? 1 : 0) != 0;
             cache_flush<NB>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad);
             __syncthreads();
+#ifdef RF_EXPERIMENT_SECTIONS
+            sec_flush += __builtin_readcyclecounter() - f0;
+#endif
         }
     }
+#ifdef RF_EXPERIMENT_SECTIONS
+    // wave clocks per section: [8] waiting for the hop's records + face hit, [9] backward_segment, [10] merge + cache
+    // updates of the step, [11] barriers + flush of the epochs, [12] the whole walk, [13] wave-steps
+    if (p.stats && (threadIdx.x & 63u) == 0u) {
+        atomicAdd(p.stats + 8, W.sec_wait);
+        atomicAdd(p.stats + 9, W.sec_segment);
+        atomicAdd(p.stats + 10, sec_cache);
+        atomicAdd(p.stats + 11, sec_flush);
+        atomicAdd(p.stats + 12, (unsigned long long)__builtin_readcyclecounter() - sec_total);
+        atomicAdd(p.stats + 13, sec_steps);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1587,10 +1616,9 @@ __device__ __forceinline__ void table_add(unsigned long long *tab, uint32_t key,
 // same lines (a lane walking along its row).  So here every contribution goes straight to memory,
 // shaped for the atomic unit: a colour row as ONE instruction whose lanes are the row's columns -- the
 // lanes' rows are transposed through a small LDS staging area of the wave (written lane-major, read
-// column-major, two rows per pass); the point gradient as three scattered atomics per lane.  Only the
-// density gradient -- one value per segment, 10 of the 13 ms when sent directly -- still goes through
-// a block-level table: 768 cells x one double, same-cell lanes pre-merged by DPP, entries untouched
-// for 4 steps flushed as single atomics (13.1 -> 8.1 ms).
+// column-major).  The scalars per cell -- the density gradient, one value per segment and 10 of the 13 ms
+// when sent directly, and the three point-gradient components -- go through block-level write-back tables
+// (table_add above; same-cell lanes pre-merged by DPP).
 template <int DEG, bool HALF, bool QUANT>
 __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void backward_replay_direct_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
