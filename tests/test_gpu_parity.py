@@ -132,6 +132,17 @@ def test_forward_settings_and_edge_cases(foam_factory):
     out = pipe.trace_forward(p, a, adj, off, torch.zeros((0, 6), device=DEV),
                              torch.zeros((0,), dtype=torch.uint32, device=DEV))
     assert out["rgba"].shape == (0, 4)
+    # launch options outside their range are refused by the C-ABI, not guessed at
+    for knob in ("forward_mode", "backward_mode"):
+        bad = _pipeline(d)
+        setattr(bad, knob, 7)
+        with pytest.raises(RuntimeError, match=knob):
+            r, s = torch.from_numpy(rays).to(DEV), torch.full(rays.shape[:-1], int(start), dtype=torch.int64).to(torch.uint32).to(DEV)
+            f = pipe.trace_forward(p, a, adj, off, r, s)
+            if knob == "forward_mode":
+                bad.trace_forward(p, a, adj, off, r, s)
+            else:
+                bad.trace_backward(p, a, adj, off, r, s, f["rgba"], torch.ones_like(f["rgba"]))
 
 
 def _backward_case(foam_factory, d, seed, image, quantiles, with_error, n_points=5000):
