@@ -14,8 +14,10 @@ d = sys.argv[1]
 def short(name):
     m = re.search(r"rf::(\w+)(<[^>]*>)?", name)
     base, targs = m.group(1), (m.group(2) or "")
-    # the statistics instance of the forward kernel (<..., QUANT=true, STATS=true>) is not a bench kernel
-    if base == "forward_kernel" and targs.rstrip(">").endswith("true, true"):
+    # the statistics instance of the forward kernel (<DEG, HALF, BENCH, QUANT, STATS, EAGER>: STATS = true) is not a
+    # bench kernel
+    args = [a.strip() for a in targs.strip("<>").split(",")]
+    if base == "forward_kernel" and len(args) >= 5 and args[4] == "true":
         base = "forward_kernel[stats]"
     return base
 
