@@ -476,8 +476,10 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 // Waves per SIMD the register allocation is told to aim for: 6 (80 VGPRs, no spills) for the plain
 // instances up to SH degree 2 -- measured 3 % faster than leaving the choice to the compiler, which
 // lands on the same occupancy with a worse schedule; 7 / 8 (72 / 64 VGPRs, a few spills) measured 1-2 % slower --,
-// 5 for the plain SH-degree-3 instances (96 VGPRs, 11 dwords spilled outside the scan: 4M-point 4K frame 23.5 ->
-// 22.2 ms; 6 waves: 22.8) and 4 where quantile / statistics code is compiled in.
+// 5 for the plain fp32 SH-degree-3 instances (96 VGPRs, 11 dwords spilled outside the scan: 4M-point 4K frame 23.5 ->
+// 22.2 ms; 6 waves: 22.8 then, 20.26 against 20.32 with the final kernel: no difference), 6 for the fp16 ones, whose
+// rows are half as many registers (the render path, 1557x1038 at SH 3: 2.65 -> 2.53 ms: profiles/r03/q_final_bench_render.json against the final evidence) and 4
+// where quantile / statistics code is compiled in.
 #ifndef RF_FWD_WAVES_OTHER
 #define RF_FWD_WAVES_OTHER 4
 #endif
@@ -487,20 +489,23 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 #ifndef RF_FWD_WAVES_D3
 #define RF_FWD_WAVES_D3 5
 #endif
+#ifndef RF_FWD_WAVES_D3_HALF
+#define RF_FWD_WAVES_D3_HALF 6
+#endif
 // EAGER instances (the first kEagerBlocks face blocks of a cell requested at once, at the hop that enters it): 122 VGPRs
 // without spills at 4 waves per SIMD up to SH degree 2; 3 waves for degree 3 and with quantile code (measured on the
 // training batch: degree 3 forward 4.94 ms at 4 waves, 4.64 at 3; with quantiles 7.66 -- spills -- and 4.62).
 #ifndef RF_FWD_WAVES_EAGER
 #define RF_FWD_WAVES_EAGER 4
 #endif
-constexpr int forward_waves(int deg, bool quant, bool stats, bool eager) {
+constexpr int forward_waves(int deg, bool half, bool quant, bool stats, bool eager) {
     if (eager) return (deg <= 2 && !quant) ? RF_FWD_WAVES_EAGER : 3;
     if (quant || stats) return RF_FWD_WAVES_OTHER;
-    return deg <= 2 ? RF_FWD_WAVES_MAIN : RF_FWD_WAVES_D3;
+    return deg <= 2 ? RF_FWD_WAVES_MAIN : (half ? RF_FWD_WAVES_D3_HALF : RF_FWD_WAVES_D3);
 }
 
 template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS, bool EAGER>
-__global__ __launch_bounds__(kBlock, forward_waves(DEG, QUANT, STATS, EAGER)) void forward_kernel(FwdParams p) {
+__global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, EAGER)) void forward_kernel(FwdParams p) {
     const uint32_t lane = threadIdx.x & 63u;
 #ifdef RF_EXPERIMENT_TIMELINE
     const unsigned long long tl_start = wall_clock64();
