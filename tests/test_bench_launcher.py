@@ -51,6 +51,16 @@ def test_bench_launches_its_own_ranks(extra, scaling):
             assert d["detail"]["exchange"] == "dense"
 
 
+def test_bench_forward_only_frame_cut_by_rows():
+    """BASELINE config 5's multi-GPU shape: a frame cut by rows, forward only, nothing to exchange."""
+    d = _run(["--forward-only"], 2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["rays_per_step"] == 40 * 32
+    b = d["detail"]["row_bounds"]
+    assert b[0] == 0 and b[-1] == 32 and len(b) == 3
+    assert d["detail"]["backward_ms"] == 0.0
+
+
 def test_bench_single_rank_needs_no_launcher():
     d = _run([], 1)
     assert d["n_gpus"] == 1 and d["config"]["rays_per_step"] == 40 * 32
