@@ -100,6 +100,8 @@ def parse_args(argv=None):
     ap.add_argument("--weak", action="store_true", help="N>1: one frame per rank instead of one frame cut by rows")
     ap.add_argument("--exchange", choices=["sparse", "dense"], default="sparse")
     ap.add_argument("--no-rebalance", action="store_true", help="N>1: keep the even row split")
+    ap.add_argument("--tile-order", default=None,
+                    help="image workloads: Pipeline.tile_order_mode (default: the pipeline's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: CPU test of the launcher)")
@@ -302,6 +304,8 @@ def main():
         pipe = radfoam.create_pipeline(sh_degree, attr_dtype)
         pipe.backward_mode = args.backward_mode
         pipe.record_trail = not W["forward_only"]   # trace_backward is driven by hand on plain tensors
+        if args.tile_order is not None:
+            pipe.tile_order_mode = None if args.tile_order == "static" else args.tile_order
     else:
         mod, fn = test_factory.split(":")
         pipe = getattr(importlib.import_module(mod), fn)(sh_degree)

@@ -95,6 +95,16 @@ typedef struct rf_launch_opts {
                               /*   first six blocks are requested together at the hop that enters the cell (four  */
                               /*   waves per SIMD: flat batches, launches of at most 1024 blocks).  Same results  */
                               /*   bit for bit; auto picks by launch shape.                                       */
+    /* Image-shaped batches only, optional: device uint32[rf_launch_blocks(...)], the 16x16-pixel tile each block of the */
+    /* launch walks (values >= the number of tiles: the block owns no rays).  Any assignment that names every tile once  */
+    /* gives the same results; the order decides which blocks are still running when the launch drains.  Default: tiles  */
+    /* dealt to the XCDs in strips (rf_kernels.hip: dealt_tile).                                                          */
+    const uint32_t *tile_order;
+    /* rf_trace_forward / rf_trace_benchmark, optional: device uint32[number of tiles] (image-shaped batches: 16x16-pixel  */
+    /* tiles, row-major; flat batches: groups of 256 thread slots); entry t is raised (atomic max) to the step count of   */
+    /* tile t's longest ray.  The caller zeroes it.  What a tile_order for the next launches over the same rays is built  */
+    /* from.                                                                                                            */
+    uint32_t *tile_cost;
 } rf_launch_opts;
 
 /* Last error message of the calling thread ("" if none). */
@@ -105,6 +115,11 @@ uint32_t rf_attribute_dim(int sh_degree);
 
 /* Thread slots a launch over these rays uses (trail buffers are indexed by slot). */
 uint32_t rf_trail_slots(uint32_t num_rays, uint32_t image_width, uint32_t image_height);
+
+/* Blocks a launch over these rays has (the length of rf_launch_opts.tile_order) and, with `tiles` non-null (host
+ * memory, that many entries), the default assignment: tiles[b] = the tile block b walks (>= the number of tiles:
+ * none); block b runs on XCD b % 8. */
+uint32_t rf_launch_blocks(uint32_t num_rays, uint32_t image_width, uint32_t image_height, uint32_t *tiles);
 
 /* Bytes of device scratch the tracer needs for a foam of this size: 16-byte cell records,
  * the 16-byte-per-face table (fp16 neighbour offsets as in the reference's half4 table, plus

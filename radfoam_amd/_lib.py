@@ -58,6 +58,8 @@ class LaunchOpts(C.Structure):
         ("ray_order", C.c_void_p),
         ("visit_marks", C.c_void_p),
         ("forward_mode", C.c_uint32),
+        ("tile_order", C.c_void_p),
+        ("tile_cost", C.c_void_p),
     ]
 
 
@@ -69,6 +71,7 @@ SYMBOLS = {
     "rf_last_error": (C.c_char_p, []),
     "rf_attribute_dim": (_U32, [_INT]),
     "rf_trail_slots": (_U32, [_U32, _U32, _U32]),
+    "rf_launch_blocks": (_U32, [_U32, _U32, _U32, _P]),
     "rf_workspace_bytes": (C.c_size_t, [_U32, _U32, _INT, _INT]),
     "rf_build_adjacent_diff": (_INT, [_P, _U32, _U32, _P, _P, _P, _P]),
     "rf_prepare_foam": (_INT, [_INT, _INT, _U32, _P, _P, _U32, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -63,6 +63,7 @@ struct RayGrid {
     uint32_t num_rays;
     uint32_t img_w, img_h;  // 0,0: flat list
     const uint32_t *order;  // flat list only, optional: thread slot s traces ray order[s] (rf_build_ray_order)
+    const uint32_t *tile_order;  // images only, optional: block b walks tile tile_order[b] instead of dealt_tile(b)
 };
 
 struct FwdParams {
@@ -80,6 +81,7 @@ struct FwdParams {
     float *contribution;
     unsigned long long *stats;
     uint8_t *visit_marks;   // statistics instance only, optional: [N] set to 1 for every cell scanned
+    uint32_t *tile_cost;    // optional: [tiles] maximum over the launch of the steps of a tile's longest ray
     uint32_t *trail;        // [trail_cap][trail_slots] cell entered by each hop (optional)
     uint32_t *trail_hops;   // [trail_slots] hops taken by the ray of each thread slot
     uint32_t trail_cap, trail_slots;
@@ -127,7 +129,14 @@ constexpr int kBlock = 256;
 // and k chunks per image row, XCD x would only ever see the same (x mod k)-th part of every row
 // (measured with 16x4-tile blocks, 8 per row: one XCD per image column, 7.7 ms instead of 5.6).
 // The launch is padded to whole rounds of 8 chunks; blocks whose tile falls past the end own no rays.
-__device__ __forceinline__ uint32_t dealt_tile(uint32_t b, uint32_t chunk, uint32_t rounds) {
+// That is the assignment when nothing is known about the frame.  Which tiles are still running when the launch drains
+// decides its last half millisecond (a launch ends a longest-ray's chain of dependent hops after its last block
+// starts), and the frame itself says which tiles are short: the forward records the step count of every tile's longest
+// ray (rf_launch_opts.tile_cost) and the host turns that into an assignment for the next launches over the frame
+// (rf_launch_opts.tile_order; radfoam_amd/pipeline.py: tile_order) -- every XCD keeps the tiles dealt to it here but takes
+// them longest first, or keeps this order and moves the cheapest tiles to the end (1080p frame: forward 4.70 -> 4.42 ms,
+// backward 3.88 -> 3.73; the render path 2.51 -> 2.26 ms).
+inline __host__ __device__ uint32_t dealt_tile(uint32_t b, uint32_t chunk, uint32_t rounds) {
     const uint32_t x = b & 7u, i = b >> 3;
     uint32_t j = i / chunk;
     const uint32_t o = i - j * chunk;
@@ -165,7 +174,7 @@ inline uint32_t launch_blocks(const RayGrid &g) {
 // ray and trail slot of this thread; false when it owns no ray (slot == kNone: not even a slot)
 __device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray, uint32_t &slot) {
     const uint32_t chunk = tile_chunk(g);
-    const uint32_t tile = dealt_tile(blockIdx.x, chunk, gridDim.x / (8u * chunk));
+    const uint32_t tile = g.tile_order ? g.tile_order[blockIdx.x] : dealt_tile(blockIdx.x, chunk, gridDim.x / (8u * chunk));
     const uint32_t tid = threadIdx.x;
     ray = 0;
     slot = kNone;
@@ -658,6 +667,16 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, EAGE
 
     if constexpr (!BENCH) {
         if (p.trail && slot != kNone) p.trail_hops[slot] = valid ? hops : 0u;
+    }
+    // what the tile cost: the steps of its longest ray (feeds the tile order of the next launches over this frame)
+    if (p.tile_cost && slot != kNone) {
+        uint32_t longest = valid ? n : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)longest, off, 64);
+            longest = other > longest ? other : longest;
+        }
+        if (lane == 0u) atomicMax(p.tile_cost + slot / (uint32_t)kBlock, longest);
     }
     if (!valid) return;
     if constexpr (BENCH) {
@@ -2179,13 +2198,15 @@ struct LaunchBackward {
 };
 
 static RayGrid make_grid(uint32_t num_rays, const rf_launch_opts *opts) {
-    RayGrid g{num_rays, 0u, 0u, nullptr};
+    RayGrid g{num_rays, 0u, 0u, nullptr, nullptr};
     if (opts && opts->image_width && opts->image_height &&
         (uint64_t)opts->image_width * opts->image_height == num_rays) {
         g.img_w = opts->image_width;
         g.img_h = opts->image_height;
+        g.tile_order = opts->tile_order;
     } else if (opts) {
         g.order = opts->ray_order;
+        g.tile_order = opts->tile_order;
     }
     return g;
 }
@@ -2208,6 +2229,19 @@ uint32_t rf_trail_slots(uint32_t num_rays, uint32_t image_width, uint32_t image_
     o.image_width = image_width;
     o.image_height = image_height;
     return num_tiles(make_grid(num_rays, &o)) * (uint32_t)kBlock;
+}
+
+uint32_t rf_launch_blocks(uint32_t num_rays, uint32_t image_width, uint32_t image_height, uint32_t *tiles) {
+    rf_launch_opts o{};
+    o.image_width = image_width;
+    o.image_height = image_height;
+    const RayGrid g = make_grid(num_rays, &o);
+    const uint32_t nb = launch_blocks(g);
+    if (tiles) {
+        const uint32_t chunk = tile_chunk(g);
+        for (uint32_t b = 0; b < nb; ++b) tiles[b] = dealt_tile(b, chunk, nb / (8u * chunk));
+    }
+    return nb;
 }
 
 size_t rf_workspace_bytes(uint32_t num_points, uint32_t point_adjacency_size, int sh_degree,
@@ -2303,6 +2337,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     p.contribution = static_cast<float *>(point_contribution);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
     p.visit_marks = opts->stats ? opts->visit_marks : nullptr;
+    p.tile_cost = opts->tile_cost;
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: trail_slots smaller than rf_trail_slots()");
@@ -2412,7 +2447,8 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
     if (no_pixels) return RF_OK;   // workspace packed above (as for an empty ray batch)
     FwdParams p{};
     p.foam = make_view(L, opts->workspace, attributes, point_adjacency_offsets);
-    p.grid = RayGrid{camera->width * camera->height, camera->width, camera->height, nullptr};
+    p.grid = RayGrid{camera->width * camera->height, camera->width, camera->height, nullptr, opts->tile_order};
+    p.tile_cost = opts->tile_cost;
     p.settings = *settings;
     p.start = start_point_index;
     p.cam = *camera;

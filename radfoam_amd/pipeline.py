@@ -155,6 +155,41 @@ class _FoamCache:
         self.refs = None
 
 
+def tile_order(cost, default, rule):
+    """The tile every block of an image launch walks, from the static assignment `default` (rf_launch_blocks: block b ->
+    tile, values >= the number of tiles = none; block b runs on XCD b % 8) and a cost per tile (its longest ray).
+
+      "xcd"           every XCD keeps its tiles and takes them longest first;
+      "tail[:count]"  the static order, except that the `count` (2048) cheapest tiles of the frame come last, the longest
+                      of them first: what is still running when the launch drains is short, and the bulk of the launch
+                      keeps the strips of the static dealing;
+      "global"        all tiles longest first, whatever the XCD.
+    Returns int64 [len(default)]: a permutation of `default`."""
+    nt = int(cost.numel())
+    if rule == "global":
+        order = torch.full_like(default, nt)
+        order[:nt] = torch.argsort(cost, descending=True, stable=True)
+        return order
+    per_xcd = default.view(-1, 8)                                      # [position in the XCD's sequence, XCD]
+    valid = default < nt
+    c = torch.where(valid, cost[default.clamp(max=nt - 1)], torch.full_like(default, -1, dtype=cost.dtype)).view(-1, 8)
+    if rule == "xcd":
+        idx = torch.sort(c, dim=0, descending=True, stable=True).indices
+    elif rule.startswith("tail"):
+        count = int(rule.split(":")[1]) if ":" in rule else 2048
+        count = max(1, min(count, nt))
+        limit = torch.kthvalue(cost.to(torch.float32), count).values.to(cost.dtype)
+        pos = torch.arange(c.shape[0], device=c.device, dtype=torch.int64).view(-1, 1).expand_as(c)
+        big = int(c.shape[0]) + 1
+        cheap = (c >= 0) & (c <= limit)
+        key = torch.where(cheap, big + (int(2 ** 24) - c.to(torch.int64)), pos)
+        key = torch.where(c < 0, torch.full_like(key, big + int(2 ** 25)), key)
+        idx = torch.sort(key, dim=0, stable=True).indices
+    else:
+        raise ValueError(f"unknown tile order rule {rule!r}")
+    return torch.gather(per_xcd, 0, idx).reshape(-1)
+
+
 class Pipeline:
     """radfoam::Pipeline as seen from Python (pipeline_bindings.cpp:626-667)."""
 
@@ -179,6 +214,21 @@ class Pipeline:
         self.forward_mode = 0
         #: experiment builds only (scripts/): int64 device tensor handed to rf_trace_backward as rf_launch_opts.stats
         self.experiment_stats = None
+        #: image-shaped batches: the order in which the blocks of a launch take the 16x16 tiles (rf_launch_opts.tile_order),
+        #: from the hop counts of the previous forward over a frame of this shape -- any order gives the same results, the
+        #: order decides what is still running when a launch drains ("Work distribution"):
+        #:   "auto" (default)  forward: every XCD keeps the tiles the static dealing gives it but takes them longest first
+        #:                     (launches of at most 16384 blocks; larger ones as the backward); backward: the static order
+        #:                     with the cheapest 2048 tiles of the frame last; sorted flat batches (their 256-slot groups):
+        #:                     the cheapest eighth last in both launches;
+        #:   None / "static"   the static dealing of the kernels (strips of a quarter row per XCD, from both ends of the
+        #:                     frame towards its middle);
+        #:   "xcd", "tail", "tail:<count>", "global"   one rule for both launches (experiments).
+        self.tile_order_mode = "auto"
+        #: launches over a frame shape between two learnings of its tile orders when the rays keep changing (an order
+        #: learnt on another camera of the same scene is worth as much as the frame's own: scripts/gpu_tile_order_stale.py)
+        self.tile_order_refresh = 16
+        self._tiles = None
         #: trace_forward records the cell every hop enters so that a trace_backward call on the same
         #: inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).  Costs
         #: trail_steps * 4 bytes per ray of HBM (2.1 GB for a 1080p frame at 256 steps), so:
@@ -302,7 +352,8 @@ class Pipeline:
         return s
 
     # -- foam packing ---------------------------------------------------------------------------
-    def _launch_opts(self, points, attributes, adjacency, offsets, rays_shape, ext_diff=None):
+    def _launch_opts(self, points, attributes, adjacency, offsets, rays_shape, ext_diff=None, launch="forward",
+                     image=None):
         """Workspace + rf_launch_opts for this call (foam_prepared set on a cache hit)."""
         n = points.numel() // 3
         e = adjacency.numel()
@@ -328,6 +379,17 @@ class Pipeline:
         # The workspace is about to be (re)packed by the C call: until that call has succeeded the cache
         # must not claim it (a failed or never-issued launch would leave an unpacked workspace behind a
         # valid key).  _foam_done() records it afterwards.
+        # image: the frame of a trace_benchmark call, whose camera carries the shape (image_width / _height stay 0)
+        shape = (opts.image_height, opts.image_width) if opts.image_width else image
+        if shape is None and len(rays_shape) >= 1:       # a flat batch: its 256-slot groups, in the traced (sorted) order
+            n = 1
+            for d in rays_shape[:-1]:
+                n *= int(d)
+            shape = ("flat", n)
+        t = self._tiles
+        if shape and self.tile_order_mode not in (None, "static") and t is not None and t["shape"] == tuple(shape) and \
+                t.get(launch) is not None and t[launch].device == points.device:
+            opts.tile_order = t[launch].data_ptr()
         opts._pending_foam = None
         if not hit:
             opts._pending_foam = tensors if self.cache_foam else ()
@@ -491,6 +553,12 @@ class Pipeline:
         trail = None
         if self._wants_trail(points, attributes):
             trail = self._new_trail(opts, num_rays, dev)
+        tiles_pending = None
+        if opts.image_width:
+            tiles_pending = self._tile_cost_begin(opts, opts.image_height, opts.image_width,
+                                                  (self._tkey(rays_c), self._tkey(start_c)), dev)
+        elif opts.ray_order:
+            tiles_pending = self._tile_cost_begin(opts, "flat", num_rays, (self._tkey(rays_c), self._tkey(start_c)), dev)
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_forward(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),
@@ -512,6 +580,8 @@ class Pipeline:
         else:
             self._trail = None
 
+        self._tile_cost_end(tiles_pending)
+
         out = {"rgba": rgba}
         if quantiles_c is not None:
             out["depth"] = depth
@@ -520,6 +590,53 @@ class Pipeline:
             out["contribution"] = contribution.to(self._attr_dtype)
         out["num_intersections"] = num_intersections
         return out
+
+    def _tile_cost_begin(self, opts, height, width, key, dev):
+        """Ask the launch about to be issued for the cost of its tiles (rf_launch_opts.tile_cost) when the tile orders of
+        this frame shape were learnt from other rays (another camera) or not at all.  Returns what _tile_cost_end needs."""
+        mode = self.tile_order_mode
+        if mode in (None, "static") or (height != "flat" and (height < 16 or width < 16)):
+            return None
+        t = self._tiles
+        if t is not None and t["shape"] == (height, width) and t["mode"] == mode and t["default"].device == dev:
+            t["age"] += 1
+            if t["key"] == key or t["age"] < int(self.tile_order_refresh):
+                return None
+        tiles = (width + 255) // 256 if height == "flat" else ((height + 15) // 16) * ((width + 15) // 16)
+        cost = torch.zeros(tiles, dtype=torch.int32, device=dev)
+        opts.tile_cost = cost.data_ptr()
+        return (height, width, key, cost)
+
+    def _tile_cost_end(self, pending):
+        """Tile orders for the next launches over a frame of this shape (all on the device, no synchronisation): a tile
+        costs what its longest ray took.  Until the rays change again the orders are reused -- and used for other rays of
+        the same frame shape meanwhile: any order is correct."""
+        if pending is None:
+            return
+        height, width, key, cost = pending
+        mode = self.tile_order_mode
+        dev = cost.device
+        t = self._tiles
+        if t is None or t["shape"] != (height, width) or t["default"].device != dev:
+            dims = (width, 0, 0) if height == "flat" else (height * width, width, height)
+            nb = int(self._lib.rf_launch_blocks(*dims, None))
+            host = (C.c_uint32 * nb)()
+            self._lib.rf_launch_blocks(*dims, host)
+            t = {"shape": (height, width), "default": torch.tensor(list(host), dtype=torch.int64, device=dev)}
+        default = t["default"]
+        if mode != "auto":
+            rules = (mode, mode)
+        elif height == "flat":
+            # the 256-slot groups of a sorted batch: the cheapest eighth last, in both launches.  What one batch teaches
+            # holds for the next batches of the same cameras (the sort key is camera, then direction): on the training
+            # batch of bench.py forward + backward 11.35 ms with the static order, 10.88 with its own, 11.02 with
+            # another batch's (scripts/gpu_flat_tile_order.py); longest-first within the XCDs does not transfer
+            rules = ("tail:%d" % max(8, int(cost.numel()) // 8),) * 2
+        else:
+            rules = ("xcd" if default.numel() <= 16384 else "tail", "tail")
+        orders = {rule: tile_order(cost, default, rule).to(torch.int32).contiguous() for rule in set(rules)}
+        t.update(key=key, mode=mode, age=0, forward=orders[rules[0]], backward=orders[rules[1]])
+        self._tiles = t
 
     # -- trace_backward --------------------------------------------------------------------------
     def trace_backward(self, points, attributes, point_adjacency, point_adjacency_offsets, rays,
@@ -623,7 +740,7 @@ class Pipeline:
                 out["point_error"] = point_error.to(self._attr_dtype)
             return out
 
-        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
+        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape, launch="backward")
         self._ray_order(opts, rays_c, start_c, num_rays)
         tr = self._trail
         if tr is not None and tr["order"] == opts.ray_order and \
@@ -702,8 +819,11 @@ class Pipeline:
             raise RuntimeError("output_rgba must be contiguous (it is written in place)")
         settings = self._settings(weight_threshold, max_intersections)
 
-        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, (), ext_diff=diff_c)
+        opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, (), ext_diff=diff_c,
+                                 image=(cam.height, cam.width))
         dev = points_c.device
+        cam_key = ("camera", bytes(cam), self._tkey(start_point))
+        tiles_pending = self._tile_cost_begin(opts, cam.height, cam.width, cam_key, dev)
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_benchmark(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),
@@ -711,6 +831,7 @@ class Pipeline:
                 C.byref(cam), _ptr(start_point), _ptr(output_rgba), C.byref(opts), _stream_ptr(dev))
         _lib.check(rc)
         self._foam_done(opts)
+        self._tile_cost_end(tiles_pending)
         return None
 
     # -- extras (no reference counterpart) -------------------------------------------------------

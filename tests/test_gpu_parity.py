@@ -235,6 +235,72 @@ def test_short_and_ragged_images(foam_factory, width, height):
             assert ok and rel < 1e-5, (mode, key, rel, worst)
 
 
+@pytest.mark.parametrize("rule", ["auto", "xcd", "tail:7", "global", "reversed"])
+def test_tile_order_does_not_change_results(foam_factory, rule):
+    """The blocks of an image launch take the tiles in an order learnt from the previous frame's hop counts
+    (Pipeline.tile_order_mode, rf_launch_opts.tile_order); any order -- the static one backwards included -- gives the same
+    forward bit for bit and the same gradients."""
+    d = 2
+    fm = foam_factory(6000, d, 41)
+    cam, rays, start = H.camera_setup(fm, 200, 136)
+    starts = np.full(rays.shape[:-1], start, dtype=np.uint32)
+    g = np.random.default_rng(9).normal(size=rays.shape[:-1] + (4,)).astype(np.float32)
+    args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    fwd = O.trace_forward(*args, rays, starts)
+    ref = O.trace_backward(*args, rays, starts, fwd["rgba"], g, num_threads=1)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    t = lambda x: torch.from_numpy(x).to(DEV)
+    tr, ts, tg = t(rays), t(starts), t(g)
+    pipe = _pipeline(d)
+    pipe.tile_order_mode = "auto" if rule == "reversed" else rule
+    pipe.trace_forward(p, a, adj, off, tr, ts)                  # the frame the orders are learnt from
+    tiles = pipe._tiles
+    assert tiles is not None and tiles["shape"] == (136, 200)
+    nt = 13 * 9
+    for which in ("forward", "backward"):
+        o = tiles[which].cpu().numpy().astype(np.int64)
+        assert sorted(o[o < nt].tolist()) == list(range(nt))
+    if rule == "reversed":
+        tiles["forward"] = torch.flip(tiles["default"], dims=(0,)).to(torch.int32).contiguous()
+        tiles["backward"] = tiles["forward"]
+    f = pipe.trace_forward(p, a, adj, off, tr, ts)
+    np.testing.assert_array_equal(f["rgba"].cpu().numpy().view(np.uint32), fwd["rgba"].view(np.uint32))
+    np.testing.assert_array_equal(f["num_intersections"].cpu().numpy().view(np.uint32), fwd["num_intersections"])
+    out = pipe.trace_backward(p, a, adj, off, tr, ts, f["rgba"], tg)
+    for key in ("points_grad", "attr_grad"):
+        ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+        assert ok and rel < 1e-5, (rule, key, rel, worst)
+
+
+def test_tile_order_of_a_sorted_flat_batch(foam_factory):
+    """Flat batches large enough to be traced in the sorted order also learn an order for their 256-slot groups; the second
+    batch (other rays, same size) is traced in the order the first one taught, with the same results as ever."""
+    d = 1
+    fm = foam_factory(6000, d, 43)
+    args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    pipe = _pipeline(d)
+    pipe.reorder_min_rays = 1024
+    t = lambda x: torch.from_numpy(x).to(DEV)
+    for seed in (5, 6):
+        rays, starts = H.random_rays(fm, 20000, seed=seed)
+        g = np.random.default_rng(seed).normal(size=(20000, 4)).astype(np.float32)
+        fwd = O.trace_forward(*args, rays, starts)
+        ref = O.trace_backward(*args, rays, starts, fwd["rgba"], g, num_threads=1)
+        tr, ts = t(rays), t(starts)
+        f = pipe.trace_forward(p, a, adj, off, tr, ts)
+        np.testing.assert_array_equal(f["rgba"].cpu().numpy().view(np.uint32), fwd["rgba"].view(np.uint32))
+        out = pipe.trace_backward(p, a, adj, off, tr, ts, f["rgba"], t(g))
+        for key in ("points_grad", "attr_grad"):
+            ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+            assert ok and rel < 1e-5, (seed, key, rel, worst)
+        tiles = pipe._tiles
+        assert tiles is not None and tiles["shape"] == ("flat", 20000)
+        o = tiles["forward"].cpu().numpy().astype(np.int64)
+        nt = (20000 + 255) // 256
+        assert sorted(o[o < nt].tolist()) == list(range(nt))
+
+
 @pytest.mark.parametrize("mode", [2, 3])
 def test_backward_with_zero_weight_threshold(foam_factory, mode):
     """weight_threshold = 0 on an opaque foam: the transmittance in the compositing denominators decays
@@ -316,6 +382,14 @@ def test_benchmark_path(foam_factory, d, half):
     pipe.trace_benchmark(p, a, adj, off, dtab, camera, sp, out, weight_threshold=0.05)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), ref)
+    # the second frame of the same camera is walked in the tile order the first one taught (Pipeline.tile_order_mode)
+    tiles = pipe._tiles
+    assert tiles is not None and tiles["shape"] == (60, 100) and int(tiles["forward"].numel()) % 8 == 0
+    out.zero_()
+    pipe.trace_benchmark(p, a, adj, off, dtab, camera, sp, out, weight_threshold=0.05)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), ref)
+    assert pipe._tiles is tiles      # same camera: nothing recomputed
     # fisheye: device sin/cos/atan2 differ from glibc by ulps -> channels within 1 LSB
     cam_f = dict(cam)
     cam_f["model"] = "fisheye"

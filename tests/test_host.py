@@ -44,8 +44,8 @@ def test_struct_layouts_match_header():
     assert _lib.LaunchOpts.foam_prepared.offset == 16 and _lib.LaunchOpts.stats.offset == 32
     assert _lib.LaunchOpts.trail.offset == 40 and _lib.LaunchOpts.trail_cap.offset == 56
     assert _lib.LaunchOpts.ray_order.offset == 64 and _lib.LaunchOpts.visit_marks.offset == 72
-    assert _lib.LaunchOpts.forward_mode.offset == 80
-    assert ctypes.sizeof(_lib.LaunchOpts) == 88
+    assert _lib.LaunchOpts.forward_mode.offset == 80 and _lib.LaunchOpts.tile_order.offset == 88
+    assert _lib.LaunchOpts.tile_cost.offset == 96 and ctypes.sizeof(_lib.LaunchOpts) == 104
 
 
 def test_host_only_entry_points():
@@ -292,3 +292,49 @@ def test_the_committed_counters_describe_the_committed_kernel_sources():
     committed = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "counters.json")))
     assert committed["north-star"]["csrc_sha256"] == hip_build.source_hash(), \
         "kernel sources changed after the last PMC passes: re-run scripts/gpu_evidence.sh pmc + update_profiles.py"
+
+
+def test_tile_orders_are_permutations_of_the_static_assignment():
+    """rf_launch_opts.tile_order (Pipeline.tile_order_mode): whatever the rule, every tile is named exactly once, and the
+    rules that keep the static dealing's XCD sets keep them."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from radfoam_amd import _lib
+    from radfoam_amd.pipeline import tile_order
+
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for width, height in ((1920, 1080), (200, 136), (96, 40), (33, 17)):
+        nb = int(lib.rf_launch_blocks(width * height, width, height, None))
+        host = (ctypes.c_uint32 * nb)()
+        assert lib.rf_launch_blocks(width * height, width, height, host) == nb and nb % 8 == 0
+        default = torch.tensor(list(host), dtype=torch.int64)
+        nt = ((width + 15) // 16) * ((height + 15) // 16)
+        assert sorted(default[default < nt].tolist()) == list(range(nt))
+        cost = torch.from_numpy(rng.integers(1, 300, size=nt).astype(np.int32))
+        for rule in ("xcd", "tail", "tail:5", "global"):
+            order = tile_order(cost, default, rule)
+            assert order.shape == default.shape
+            assert sorted(order[order < nt].tolist()) == list(range(nt)), (rule, width, height)
+            if rule != "global":
+                for x in range(8):
+                    assert sorted(order[x::8].tolist()) == sorted(default[x::8].tolist())
+            if rule == "xcd":
+                for x in range(8):
+                    col = order[x::8]
+                    c = cost[col[col < nt]].tolist()
+                    assert c == sorted(c, reverse=True)
+                    assert bool((col[len(c):] >= nt).all())     # blocks without a tile come last
+            if rule == "tail:5" and nt > 40:
+                # the five cheapest tiles of the frame are the last tiles of their XCDs' sequences
+                limit = sorted(cost.tolist())[4]
+                for x in range(8):
+                    col = order[x::8]
+                    col = col[col < nt]
+                    cheap = (cost[col] <= limit).tolist()
+                    assert cheap == sorted(cheap)               # False ... False True ... True
+    with pytest.raises(ValueError):
+        tile_order(cost, default, "sideways")
