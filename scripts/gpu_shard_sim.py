@@ -31,6 +31,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--forward-only", action="store_true", help="BASELINE config 5: --points 4000000 --seed 4 --sh-degree 3 --width 3840 --height 2160 --forward-only")
 ap.add_argument("--worlds", type=int, nargs="+", default=[1, 2, 4, 8])
 ap.add_argument("--cuts", nargs="+", default=["balanced", "even"])
+ap.add_argument("--forward-mode", type=int, default=0, help="Pipeline.forward_mode of the ranks (0 auto, 1, 2)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 d = args.sh_degree
@@ -55,6 +56,7 @@ adj, off = torch.from_numpy(fm["point_adjacency"]).to(dev), torch.from_numpy(fm[
 g = torch.randn(rays.shape[:-1] + (4,), generator=torch.Generator().manual_seed(1234)).to(dev)
 pipe = radfoam.create_pipeline(d)
 pipe.record_trail = not args.forward_only
+pipe.forward_mode = args.forward_mode
 A = pipe.attribute_dim()
 n = p.shape[0]
 ev = lambda: torch.cuda.Event(enable_timing=True)
