@@ -432,6 +432,8 @@ def main():
     # ---- untimed extras: exact walk counters, compulsory-traffic floor, full pack -----------------
     detail = {"forward_ms": round(fwd_ms, 4), "backward_ms": round(bwd_ms, 4), "foam_pack_ms": round(pack_ms, 4),
               "setup_seconds": round(setup_s, 1), "foam_csr": fm["csr_source"]}
+    # the scheduling of the launches' blocks, learnt in the warm-up steps from the step counts of the walk itself
+    detail["tile_order"] = getattr(pipe, "tile_order_mode", None) or "static"
     detail.update(tri_ms)
     if world > 1:
         detail["exchange_ms"] = round(exch_ms, 4)
