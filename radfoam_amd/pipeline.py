@@ -228,7 +228,8 @@ class Pipeline:
         #: launches over a frame shape between two learnings of its tile orders when the rays keep changing (an order
         #: learnt on another camera of the same scene is worth as much as the frame's own: scripts/gpu_tile_order_stale.py)
         self.tile_order_refresh = 16
-        self._tiles = None
+        self._tiles = None          # the tile orders used last (one entry of _tile_sets)
+        self._tile_sets = {}        # frame shape -> its tile orders (a few shapes: training batches, evaluation frames)
         #: trace_forward records the cell every hop enters so that a trace_backward call on the same
         #: inputs replays it instead of re-scanning every cell (rf_launch_opts.trail).  Costs
         #: trail_steps * 4 bytes per ray of HBM (2.1 GB for a 1080p frame at 256 steps), so:
@@ -386,10 +387,11 @@ class Pipeline:
             for d in rays_shape[:-1]:
                 n *= int(d)
             shape = ("flat", n)
-        t = self._tiles
-        if shape and self.tile_order_mode not in (None, "static") and t is not None and t["shape"] == tuple(shape) and \
-                t.get(launch) is not None and t[launch].device == points.device:
+        t = self._tile_sets.get(tuple(shape)) if shape else None
+        if t is not None and self.tile_order_mode not in (None, "static") and t["mode"] == self.tile_order_mode and \
+                t[launch].device == points.device:
             opts.tile_order = t[launch].data_ptr()
+            self._tiles = t
         opts._pending_foam = None
         if not hit:
             opts._pending_foam = tensors if self.cache_foam else ()
@@ -597,8 +599,8 @@ class Pipeline:
         mode = self.tile_order_mode
         if mode in (None, "static") or (height != "flat" and (height < 16 or width < 16)):
             return None
-        t = self._tiles
-        if t is not None and t["shape"] == (height, width) and t["mode"] == mode and t["default"].device == dev:
+        t = self._tile_sets.get((height, width))
+        if t is not None and t["mode"] == mode and t["default"].device == dev:
             t["age"] += 1
             if t["key"] == key or t["age"] < int(self.tile_order_refresh):
                 return None
@@ -616,8 +618,8 @@ class Pipeline:
         height, width, key, cost = pending
         mode = self.tile_order_mode
         dev = cost.device
-        t = self._tiles
-        if t is None or t["shape"] != (height, width) or t["default"].device != dev:
+        t = self._tile_sets.get((height, width))
+        if t is None or t["default"].device != dev:
             dims = (width, 0, 0) if height == "flat" else (height * width, width, height)
             nb = int(self._lib.rf_launch_blocks(*dims, None))
             host = (C.c_uint32 * nb)()
@@ -636,6 +638,10 @@ class Pipeline:
             rules = ("xcd" if default.numel() <= 16384 else "tail", "tail")
         orders = {rule: tile_order(cost, default, rule).to(torch.int32).contiguous() for rule in set(rules)}
         t.update(key=key, mode=mode, age=0, forward=orders[rules[0]], backward=orders[rules[1]])
+        self._tile_sets.pop((height, width), None)
+        while len(self._tile_sets) >= 8:                    # a handful of frame shapes at most
+            self._tile_sets.pop(next(iter(self._tile_sets)))
+        self._tile_sets[(height, width)] = t
         self._tiles = t
 
     # -- trace_backward --------------------------------------------------------------------------
