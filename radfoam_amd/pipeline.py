@@ -159,7 +159,7 @@ def tile_order(cost, default, rule):
     """The tile every block of an image launch walks, from the static assignment `default` (rf_launch_blocks: block b ->
     tile, values >= the number of tiles = none; block b runs on XCD b % 8) and a cost per tile (its longest ray).
 
-      "xcd"           every XCD keeps its tiles and takes them longest first;
+      "xcd[:n]"       every XCD keeps its tiles and takes them longest first (in classes of n steps, static order within);
       "tail[:count]"  the static order, except that the `count` (2048) cheapest tiles of the frame come last, the longest
                       of them first: what is still running when the launch drains is short, and the bulk of the launch
                       keeps the strips of the static dealing;
@@ -175,6 +175,10 @@ def tile_order(cost, default, rule):
     c = torch.where(valid, cost[default.clamp(max=nt - 1)], torch.full_like(default, -1, dtype=cost.dtype)).view(-1, 8)
     if rule == "xcd":
         idx = torch.sort(c, dim=0, descending=True, stable=True).indices
+    elif rule.startswith("xcd:"):
+        # longest first in classes of <n> steps; tiles of a class keep the static order (neighbours stay together)
+        q = max(1, int(rule.split(":")[1]))
+        idx = torch.sort(torch.div(c, q, rounding_mode="floor"), dim=0, descending=True, stable=True).indices
     elif rule.startswith("tail"):
         count = int(rule.split(":")[1]) if ":" in rule else 2048
         count = max(1, min(count, nt))
