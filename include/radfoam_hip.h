@@ -95,10 +95,13 @@ typedef struct rf_launch_opts {
                               /*   first six blocks are requested together at the hop that enters the cell (four  */
                               /*   waves per SIMD: flat batches, launches of at most 1024 blocks).  Same results  */
                               /*   bit for bit; auto picks by launch shape.                                       */
-    /* Image-shaped batches only, optional: device uint32[rf_launch_blocks(...)], the 16x16-pixel tile each block of the */
-    /* launch walks (values >= the number of tiles: the block owns no rays).  Any assignment that names every tile once  */
-    /* gives the same results; the order decides which blocks are still running when the launch drains.  Default: tiles  */
-    /* dealt to the XCDs in strips (rf_kernels.hip: dealt_tile).                                                          */
+    /* Optional: device uint32[rf_launch_blocks(...)], the tile each block of the launch walks -- a 16x16-pixel tile of   */
+    /* an image-shaped batch, a group of 256 consecutive thread slots of a flat one (values >= the number of tiles: the   */
+    /* block owns no rays).  It MUST name every tile exactly once; the library does not check it (the table lives on the */
+    /* device).  A tile that is left out is not traced: its rays' outputs (rgba, depths, num_intersections, trail hop     */
+    /* counts) keep whatever the buffers held; a tile named twice is walked twice, which is harmless in the forward and   */
+    /* DOUBLES its rays' gradients in rf_trace_backward.  Any permutation gives the same results; the order decides which */
+    /* blocks are still running when the launch drains.  Default: tiles dealt to the XCDs in strips (dealt_tile).         */
     const uint32_t *tile_order;
     /* rf_trace_forward / rf_trace_benchmark, optional: device uint32[number of tiles] (image-shaped batches: 16x16-pixel  */
     /* tiles, row-major; flat batches: groups of 256 thread slots); entry t is raised (atomic max) to the step count of   */

@@ -383,6 +383,10 @@ __device__ __forceinline__ void face_offset(const float4 &p, const float4 &q, fl
 // ------------------------------------------------------------------------------------------
 // colour of a cell for this ray     reference: load_sh_as_rgb, sh_utils.cuh:72-83 (+ :50-54)
 
+struct __attribute__((packed, aligned(4))) Float4U {   // four floats at a 4-byte aligned address
+    float x, y, z, w;
+};
+
 template <int DEG, bool HALF>
 __device__ __forceinline__ void cell_rgb(const FoamView &fv, uint32_t cell,
                                          const float (&sh)[sh_dim(DEG)], float &r, float &g,
@@ -402,11 +406,13 @@ __device__ __forceinline__ void cell_rgb(const FoamView &fv, uint32_t cell,
             c[4 * i + 3] = half_hi(w.y);
         }
     } else {
-        const float4 *row = reinterpret_cast<const float4 *>(
+        // rows of odd pitch (A = 13, 49) are only 4-byte aligned: the load is declared as such (one global_load_dwordx4
+        // all the same: the hardware serves it in its unaligned access mode, scripts/probe/unaligned.hip)
+        const Float4U *row = reinterpret_cast<const Float4U *>(
             reinterpret_cast<const float *>(fv.sh) + (size_t)cell * fv.sh_stride);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            float4 w = row[i];
+            const Float4U w = row[i];
             c[4 * i + 0] = w.x;
             c[4 * i + 1] = w.y;
             c[4 * i + 2] = w.z;

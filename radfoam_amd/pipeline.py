@@ -244,13 +244,30 @@ class Pipeline:
         #:   True / False      always / never (callers that drive trace_backward by hand, like
         #:                     bench.py, set True).
         self.record_trail = "auto"
+        #: what "auto" cannot see from inside another operator's forward: a caller that optimises ONLY the points
+        #: (attributes frozen) through an autograd.Function -- grad mode is off there and the attributes do not require
+        #: grad, so the heuristic says "no trail" and every backward re-walks.  An operator that knows whether a backward
+        #: will follow sets this around its trace_forward call (radfoam_amd/render.py does, from ctx.needs_input_grad);
+        #: None = use the heuristic.
+        self.backward_hint = None
         #: hops recorded per ray; rays that take more are left to a second launch that walks them again by scanning.
         #: That launch is as long as its longest ray (hundreds of dependent scans): 130 of 1 M rays of the training-shaped
         #: batch take 257-269 hops and cost 1.4 ms of an 8 ms backward.  So the capacity follows the data: every
         #: trace_forward leaves the largest hop count of its batch in pinned host memory (asynchronously, no stream
-        #: synchronisation), and the next one that finds it there sizes its trail for it (trail_steps_limit at most).
+        #: synchronisation), and the next one that finds it there sizes its trail for it -- within trail_steps_limit AND
+        #: within a memory budget (the trail is trail_steps * slots * 4 bytes: one ray that runs into the default
+        #: max_intersections = 1024 would otherwise take a 1080p trail from 2.1 to 9.5 GB), and down again when the
+        #: batches get shorter (trail_shrink_after consecutive probes that need less than 3/4 of it; never below
+        #: trail_steps_floor).  Any capacity is correct: what does not fit is re-walked.  When the probe lands relative to
+        #: the next call is a matter of timing, so the capacity of a given step is not reproducible; results are.
         self.trail_steps = 256
+        self.trail_steps_floor = 256
         self.trail_steps_limit = 2048
+        #: bytes the trail of one batch may take: None = trail_memory_fraction of the device's total memory
+        self.trail_memory_limit = None
+        self.trail_memory_fraction = 0.04
+        self.trail_shrink_after = 8
+        self._trail_short_probes = 0
         self._hops_probe = None
         #: drop the trail (and its memory) once a trace_backward has replayed it; off by default because
         #: the allocation is reused by the next trace_forward of the same shape (a training loop), and a
@@ -281,6 +298,8 @@ class Pipeline:
         where grad mode is the caller's -- points.requires_grad with grad mode on.  A wrong "no" only costs speed
         (trace_backward re-walks instead of replaying), never correctness."""
         if self.record_trail == "auto":
+            if self.backward_hint is not None:      # an operator that knows (ctx.needs_input_grad) said so
+                return bool(self.backward_hint)
             return bool(attributes.requires_grad or (points.requires_grad and torch.is_grad_enabled()))
         return bool(self.record_trail)
 
@@ -387,10 +406,10 @@ class Pipeline:
         # image: the frame of a trace_benchmark call, whose camera carries the shape (image_width / _height stay 0)
         shape = (opts.image_height, opts.image_width) if opts.image_width else image
         if shape is None and len(rays_shape) >= 1:       # a flat batch: its 256-slot groups, in the traced (sorted) order
-            n = 1
+            batch_rays = 1
             for d in rays_shape[:-1]:
-                n *= int(d)
-            shape = ("flat", n)
+                batch_rays *= int(d)
+            shape = ("flat", batch_rays)
         t = self._tile_sets.get(tuple(shape)) if shape else None
         if t is not None and self.tile_order_mode not in (None, "static") and t["mode"] == self.tile_order_mode and \
                 t[launch].device == points.device:
@@ -468,26 +487,53 @@ class Pipeline:
 
     def _probe_hops(self, hops):
         """Largest hop count of the batch just traced -> pinned host memory, without waiting for it."""
+        dev = hops.device
         pr = self._hops_probe
-        if pr is None:
-            pr = self._hops_probe = {"host": torch.zeros((), dtype=torch.int32).pin_memory(), "event": None}
+        if pr is None or pr["device"] != dev:
+            pr = self._hops_probe = {"host": torch.zeros((), dtype=torch.int32).pin_memory(), "event": None,
+                                     "device": dev, "fresh": False}
         if pr["event"] is not None and not pr["event"].query():
             return                      # the previous probe has not landed yet: one in flight is enough
-        pr["host"].copy_(hops.max(), non_blocking=True)
-        pr["event"] = torch.cuda.Event()
-        pr["event"].record()
+        # on the device (and its current stream) the hops were written on, whatever the caller's current device is
+        with torch.cuda.device(dev):
+            pr["host"].copy_(hops.max(), non_blocking=True)
+            pr["event"] = torch.cuda.Event()
+            pr["event"].record(torch.cuda.current_stream(dev))
+        pr["fresh"] = True
+
+    def _trail_budget_steps(self, slots, dev) -> int:
+        """Hops per ray that fit the trail's memory budget for a launch of `slots` thread slots."""
+        limit = self.trail_memory_limit
+        if limit is None:
+            limit = int(self.trail_memory_fraction * torch.cuda.get_device_properties(dev).total_memory)
+        return max(1, int(limit) // (4 * max(int(slots), 1)))
+
+    def _fit_trail_steps(self, longest: int) -> int:
+        return (int(longest) * 9 // 8 + 31) // 32 * 32
 
     def _grow_trail_steps(self):
+        """Follow the longest ray of the last probed batch: up at once, down after trail_shrink_after short probes."""
         pr = self._hops_probe
-        if pr is not None and pr["event"] is not None and pr["event"].query():
-            longest = int(pr["host"])
-            if longest > int(self.trail_steps):
-                self.trail_steps = min((longest * 9 // 8 + 31) // 32 * 32, int(self.trail_steps_limit))
+        if pr is None or pr["event"] is None or not pr["fresh"] or not pr["event"].query():
+            return
+        pr["fresh"] = False             # one decision per probe
+        want = self._fit_trail_steps(int(pr["host"]))
+        cur = int(self.trail_steps)
+        if want > cur:
+            self.trail_steps = min(want, int(self.trail_steps_limit))
+            self._trail_short_probes = 0
+        elif cur > int(self.trail_steps_floor) and 4 * want < 3 * cur:
+            self._trail_short_probes += 1
+            if self._trail_short_probes >= int(self.trail_shrink_after):
+                self.trail_steps = max(want, int(self.trail_steps_floor))
+                self._trail_short_probes = 0
+        else:
+            self._trail_short_probes = 0
 
     def _new_trail(self, opts, num_rays, dev):
         slots = int(self._lib.rf_trail_slots(num_rays, opts.image_width, opts.image_height))
         self._grow_trail_steps()
-        cap = max(1, int(self.trail_steps))
+        cap = max(1, min(int(self.trail_steps), self._trail_budget_steps(slots, dev)))
         old = self._trail
         if old is not None and old["trail"].shape == (cap, slots) and old["trail"].device == dev:
             trail, hops = old["trail"], old["hops"]     # reuse the allocation

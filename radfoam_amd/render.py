@@ -21,6 +21,19 @@ class ErrorBox:
 
 
 class TraceRays(torch.autograd.Function):
+    @classmethod
+    def apply(cls, pipeline, points, attributes, *rest):
+        """Whether a backward can follow is known HERE and nowhere below: inside forward() grad mode is off and
+        ctx.needs_input_grad only repeats the inputs' requires_grad flags (an nn.Parameter keeps its flag under
+        torch.no_grad()), so Pipeline._wants_trail's "auto" cannot see a caller that optimises only the points.  The
+        caller's grad mode and the two differentiable inputs decide; the pipeline gets the answer as backward_hint."""
+        keep = getattr(pipeline, "backward_hint", None)
+        pipeline.backward_hint = bool(torch.is_grad_enabled() and (points.requires_grad or attributes.requires_grad))
+        try:
+            return super().apply(pipeline, points, attributes, *rest)
+        finally:
+            pipeline.backward_hint = keep
+
     @staticmethod
     def forward(ctx, pipeline, points, attributes, point_adjacency, point_adjacency_offsets, rays,
                 start_point, depth_quantiles, return_contribution):

@@ -184,8 +184,6 @@ def test_triangulation_binding_compiles_against_the_reference_header():
 
 @needs_lib
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("RF_TEST_EXPERIMENTAL") != "1",
-                    reason="written after the round's GPU minutes were spent: RF_TEST_EXPERIMENTAL=1 runs it")
 def test_triangulation_binding_matches_the_python_path():
     """What comes out of the reference's virtual interface (permutation, point_adjacency, offsets; rebuild with and
     without `incremental`; the failure type) equals radfoam.Triangulation's."""
