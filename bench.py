@@ -55,15 +55,38 @@ HBM_PEAK_MEASURED_GBS = 6290.0  # achievable streaming copy, same guide
 NUM_SIMDS = 256 * 4             # 256 CUs x 4 SIMDs
 NUM_XCDS = 8                    # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs' GRBM instances
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # 256 CUs x 128 FMA lanes x 2 flop x 2.4 GHz (same guide)
-# Irreducible work of the forward walk, from the ISA of the shipped kernel (scripts/isa_stats.py):
-# the face scan issues 59 VALU instructions per block of four faces (72 fp32 flops among them), and a hop -- link,
-# next cell record, trail entry, compositing bookkeeping -- about 113 per lane.  useful_valu_frac below = the
-# wave-instructions these would take with every lane busy on a real (unpadded) face / a real hop, over the
-# wave-instructions the launch actually issued (SQ_INSTS_VALU): issue-slot EFFICIENCY, next to valu_issue_frac, which is
-# issue-slot UTILISATION.
+# Irreducible work of the forward walk, read off the ISA of the shipped kernel by scripts/isa_stats.py --constants
+# (profiles/isa_constants.json, with the sha256 of the sources it was compiled from): the face scan
+# issues SCAN_VALU_PER_4_FACES VALU instructions per block of four faces (SCAN_FLOP_PER_4_FACES fp32 flops among them),
+# a hop -- link, next cell record, trail entry, loop bookkeeping -- HOP_VALU_PER_LANE, a composited segment
+# COMPOSITE_VALU_PER_LANE more (SH degree 2: colour row, exp).  useful_valu_frac below = the wave-instructions these
+# would take with every lane busy on a real (unpadded) face / hop / segment, over the wave-instructions the launch
+# actually issued (SQ_INSTS_VALU): issue-slot EFFICIENCY, next to valu_issue_frac, which is issue-slot UTILISATION.
+# The literals are what the committed file holds; isa_constants() refuses to quote them when the file disagrees or was
+# made from other sources.
 SCAN_VALU_PER_4_FACES = 59
 SCAN_FLOP_PER_4_FACES = 72
-HOP_VALU_PER_LANE = 113
+HOP_VALU_PER_LANE = 82
+COMPOSITE_VALU_PER_LANE = 59
+
+
+def isa_constants():
+    """(constants or None, why not): the committed ISA figures, only if they describe the sources that are running and
+    equal the literals above."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "isa_constants.json")))
+    except (OSError, ValueError):
+        return None, "profiles/isa_constants.json missing"
+    from radfoam_amd import build as hip_build
+    if rec.get("csrc_sha256") != hip_build.source_hash():
+        return None, "profiles/isa_constants.json was made from other kernel sources: python scripts/isa_stats.py --constants"
+    want = {"scan_valu_per_4_faces": SCAN_VALU_PER_4_FACES, "scan_flop_per_4_faces": SCAN_FLOP_PER_4_FACES,
+            "hop_valu_per_lane": HOP_VALU_PER_LANE, "composite_valu_per_lane": COMPOSITE_VALU_PER_LANE}
+    got = {k: rec.get(k) for k in want}
+    if got != want:
+        return None, f"bench.py's ISA constants {want} disagree with profiles/isa_constants.json {got}"
+    return got, None
+
 
 # name -> (points, seed, sh_degree, width, height, forward_only, kind, label)
 WORKLOADS = {
@@ -103,6 +126,8 @@ def parse_args(argv=None):
     ap.add_argument("--tile-order", default=None,
                     help="image workloads: Pipeline.tile_order_mode (default: the pipeline's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default line only: skip the untimed `other_workloads` record (c2, c5, render, train-batch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: CPU test of the launcher)")
     return ap.parse_args(argv)
@@ -182,13 +207,14 @@ def training_batch(fm, num_rays, seed):
     return np.ascontiguousarray(rays[perm]), np.ascontiguousarray(starts[perm])
 
 
-def algorithmic_bytes(stats, num_rays, attr_dim, c=4, nq=0):
-    """logical bytes, no cache reuse credited, no padding, no zero atomics."""
+def algorithmic_bytes(stats, num_rays, attr_dim, c=4, nq=0, render=False):
+    """logical bytes, no cache reuse credited, no padding, no zero atomics.  render: the benchmark
+    kernel reads no ray and no start cell per pixel (camera by value) and writes one RGBA8 word."""
     cells, faces, hops = stats["cells_scanned"], stats["faces_scanned"], stats["hops"]
     seg, lit = stats["segments"], stats["segments_lit"]
     attr_read = c * (seg + (attr_dim - 1) * lit)          # density always, SH row only when lit
     walk = 8 * cells + 8 * faces + (4 + 12) * hops
-    fwd = num_rays * (24 + 4 + 4 * c + 4 + 12 * nq) + walk + attr_read
+    fwd = num_rays * (4 if render else (24 + 4 + 4 * c + 4 + 12 * nq)) + walk + attr_read
     bwd = num_rays * (24 + 4 + 8 * c + 12 * nq) + walk + attr_read + attr_read + 12 * seg
     return fwd, bwd
 
@@ -245,10 +271,63 @@ def main():
         kw = {"device_id": dev} if (on_gpu and args.backend == "nccl") else {}
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
 
+    env = dict(torch=torch, dist=dist, world=world, rank=rank, dev=dev, on_gpu=on_gpu, test_factory=test_factory)
+    W = resolve_workload(args)
+    result = run_workload(args, W, env)
+    if result is not None and on_gpu and world == 1 and args.workload == "north-star" and not W.get("custom") and \
+            not args.forward_only and not args.quantiles and not args.no_other_workloads and not args.no_cpu_baseline:
+        # the driver runs this file once, with no flags -- so that one run also observes the other
+        # BASELINE configurations (untimed extras of the north-star line; each is what `--workload <name>` prints,
+        # with fewer steps and a smaller CPU sample, reduced to the figures a reader checks first)
+        result["other_workloads"] = other_workloads(args, env)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+OTHER_WORKLOADS = ("c2", "c5", "render", "train-batch")
+
+
+def other_workloads(args, env):
+    torch = env["torch"]
+    out = {}
+    for name in OTHER_WORKLOADS:
+        sub = argparse.Namespace(**vars(args))
+        sub.workload, sub.steps, sub.warmup = name, 5, 3
+        sub.cpu_seconds = min(args.cpu_seconds, 6.0)
+        t0 = time.time()
+        try:
+            r = run_workload(sub, resolve_workload(sub), env)
+            cb, rf, det = r.get("cpu_baseline") or {}, r.get("roofline") or {}, r["detail"]
+            out[name] = {
+                "workload": r["config"]["workload"], "metric": r["metric"], "value": r["value"], "unit": r["unit"],
+                "steps": sub.steps, "warmup": sub.warmup, "ms_per_step": r["ms_per_step"],
+                "forward_ms": det.get("forward_ms"), "backward_ms": det.get("backward_ms"),
+                "foam_pack_ms": det.get("foam_pack_ms"), "foam_csr": det.get("foam_csr"),
+                "matches_gpu_bitwise": cb.get("matches_gpu_bitwise"),
+                "points_grad_rel_l2": cb.get("points_grad_rel_l2"), "attr_grad_rel_l2": cb.get("attr_grad_rel_l2"),
+                "grads_within_1e-3": (None if "points_grad_within_1e-3" not in cb else
+                                      bool(cb["points_grad_within_1e-3"] and cb["attr_grad_within_1e-3"])),
+                "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "error") if k in cb},
+                "roofline": {k: rf.get(k) for k in ("bound", "kernel", "frac", "achieved", "peak", "traffic",
+                                                    "avg_launch_ms", "algorithmic_GBps", "counters_stale")},
+                "seconds": None,
+            }
+        except Exception as exc:  # noqa: BLE001  (an extra must never take the north-star line down)
+            out[name] = {"error": repr(exc)}
+        out[name]["seconds"] = round(time.time() - t0, 1)
+        torch.cuda.empty_cache()
+    return out
+
+
+def run_workload(args, W, env):
+    """One workload measured as the module docstring says; returns the JSON record on rank 0, None elsewhere."""
+    torch, dist, world, rank, dev = env["torch"], env["dist"], env["world"], env["rank"], env["dev"]
+    on_gpu, test_factory = env["on_gpu"], env["test_factory"]
     from radfoam_amd import dist as rdist
     from radfoam_amd import foam
 
-    W = resolve_workload(args)
     strong = world > 1 and not args.weak and W["kind"] in ("image", "batch")
     sh_degree = W["sh"]
 
@@ -478,19 +557,25 @@ def main():
         }
         del tree, tree2, t_adj, t_off, m_adj, m_off, moved
     roofline = None
-    if on_gpu and W["kind"] != "render" and rank == 0:
+    if on_gpu and rank == 0:
         my_rays = tracer._shard(rays) if strong else rays
         my_start = tracer._shard(start) if strong else start
-        stats = pipe.walk_statistics(points, attributes, adjacency, offsets, my_rays, my_start, visit_marks=True)
+        is_render = W["kind"] == "render"
+        cbytes = 2 if attr_dtype == torch.float16 else 4
+        # render: the camera's rays through the statistics instance of trace_forward (same walk, same threshold; the
+        # render kernel itself casts them from the camera and keeps no counters)
+        stats = pipe.walk_statistics(points, attributes, adjacency, offsets, my_rays, my_start, visit_marks=True,
+                                     weight_threshold=0.05 if is_render else None)
         visited = stats.pop("visited")
-        bytes_fwd, bytes_bwd = algorithmic_bytes(stats, local_rays, A, nq=nq)
+        bytes_fwd, bytes_bwd = algorithmic_bytes(stats, local_rays, A, c=cbytes, nq=nq, render=is_render)
         deg = (offsets[1:].to(torch.int64) - offsets[:-1].to(torch.int64))
         padded = (deg + 3) // 4 * 4
         n_vis = int(visited.sum())
         lit = visited & (attributes[:, -1] > 1e-6)
-        sh_bytes = 4 * (A - 1) * int(lit.sum())
+        sh_bytes = cbytes * (A - 1) * int(lit.sum())
         trail_bytes = 4 * stats["hops"] + 4 * local_rays if not W["forward_only"] else 0
-        comp_fwd = 16 * n_vis + 6 * int(padded[visited].sum()) + 12 * n_vis + sh_bytes + local_rays * (24 + 4 + 16 + 4) \
+        per_ray_io = 4 if is_render else (24 + 4 + 4 * cbytes + 4)    # render: camera by value, one RGBA8 word out
+        comp_fwd = 16 * n_vis + 6 * int(padded[visited].sum()) + 12 * n_vis + sh_bytes + local_rays * per_ray_io \
             + trail_bytes
         comp_bwd = None
         if last.get("res") is not None:
@@ -517,9 +602,7 @@ def main():
         roofline = build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, comp_bwd, stats)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
+        return None
 
     mode = "forward only" if W["forward_only"] else "forward+backward"
     if W["kind"] == "image":
@@ -571,15 +654,16 @@ def main():
         result["data"] = "synthetic (launcher self-test on CPU tensors through " + test_factory + ": not a measurement)"
 
     # ---- CPU baseline: the oracle on a bounded sample of the same rays --------------------------
-    if on_gpu and not args.no_cpu_baseline and world == 1 and W["kind"] != "render":
+    if on_gpu and not args.no_cpu_baseline and world == 1:
         try:
-            result["cpu_baseline"] = cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba,
-                                                  (points, attributes, adjacency, offsets), quantiles, depth_grad)
+            if W["kind"] == "render":
+                result["cpu_baseline"] = cpu_baseline_render(W, fm, cam, start_np, render_out)
+            else:
+                result["cpu_baseline"] = cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba,
+                                                      (points, attributes, adjacency, offsets), quantiles, depth_grad)
         except Exception as exc:  # the baseline must never take the bench line down
             result["cpu_baseline"] = {"error": repr(exc)}
-    print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return result
 
 
 def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, comp_bwd, walk=None):
@@ -602,6 +686,7 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
         # it is quoted (frac = null); the live figures (launch times, algorithmic and compulsory bytes) stay
         counters = {"source": counters.get("source"), "kernels": {}}
     per_kernel = {}
+    isa, isa_why = isa_constants()
     legs = [("forward_kernel", fwd_ms, bytes_fwd, comp_fwd)]
     if bwd_ms > 0:
         bwd_name = "backward_replay_direct_kernel" if W["kind"] == "batch" else "backward_replay_cached_kernel"
@@ -610,8 +695,8 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
         k = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(alg),
              "algorithmic_GBps": round(alg / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
              "compulsory_bytes_per_launch": int(comp) if comp is not None else None}
-        if name == "forward_kernel" and walk and ms > 0:   # live: the scan's arithmetic over the launch time
-            tf = SCAN_FLOP_PER_4_FACES / 4.0 * walk["faces_scanned"] / (ms * 1e-3) / 1e12
+        if name == "forward_kernel" and walk and ms > 0 and isa:   # live: the scan's arithmetic over the launch time
+            tf = isa["scan_flop_per_4_faces"] / 4.0 * walk["faces_scanned"] / (ms * 1e-3) / 1e12
             k["scan_fp32_TFLOPs"] = round(tf, 2)
             k["fp32_frac_of_peak"] = round(tf / FP32_VECTOR_PEAK_TFLOPS, 4)
         c = (counters or {}).get("kernels", {}).get(name)
@@ -621,13 +706,15 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
                 k["valu_issue_frac"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (NUM_SIMDS * cycles), 4)
                 k["valu_insts_per_launch"] = int(c.get("SQ_INSTS_VALU", 0))
                 k["effective_clock_GHz_profiled"] = round(cycles / c["duration_ns"], 3) if c.get("duration_ns") else None
-                if name == "forward_kernel" and walk and c.get("SQ_INSTS_VALU"):
-                    scan = SCAN_VALU_PER_4_FACES / 4.0 * walk["faces_scanned"] / 64.0
-                    useful = scan + HOP_VALU_PER_LANE * walk["hops"] / 64.0
-                    k["useful_valu_frac"] = round(useful / c["SQ_INSTS_VALU"], 4)
+                if name == "forward_kernel" and walk and c.get("SQ_INSTS_VALU") and isa:
+                    scan = isa["scan_valu_per_4_faces"] / 4.0 * walk["faces_scanned"] / 64.0
                     k["useful_scan_valu_frac"] = round(scan / c["SQ_INSTS_VALU"], 4)   # the face tests alone
-                    k["useful_share_of_issue_capacity"] = round(k["useful_valu_frac"] * k["valu_issue_frac"], 4)
                     k["useful_scan_share_of_issue_capacity"] = round(k["useful_scan_valu_frac"] * k["valu_issue_frac"], 4)
+                    if W["sh"] == 2:      # hop / segment counts are those of the SH-degree-2 fp32 instance
+                        useful = scan + (isa["hop_valu_per_lane"] * walk["hops"] +
+                                         isa["composite_valu_per_lane"] * walk["segments_lit"]) / 64.0
+                        k["useful_valu_frac"] = round(useful / c["SQ_INSTS_VALU"], 4)
+                        k["useful_share_of_issue_capacity"] = round(k["useful_valu_frac"] * k["valu_issue_frac"], 4)
             if c.get("hbm_bytes") is not None and ms > 0:
                 gbps = c["hbm_bytes"] / (ms * 1e-3) / 1e9
                 k["hbm_bytes_per_launch"] = int(c["hbm_bytes"])
@@ -644,7 +731,7 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
     # atomic units and on dependent gathers with both fractions low; it is labelled as what it is
     vf, hf = d.get("valu_issue_frac"), d.get("hbm_frac_of_measured_peak")
     if vf is None and hf is None:
-        bound = "valu_issue"          # no committed counters for this workload: the walk kernels' usual bound
+        bound = None                  # no committed counters for this workload (or stale ones): nothing is assumed
     elif (vf or 0.0) >= 0.5 and (vf or 0.0) >= (hf or 0.0):
         bound = "valu_issue"
     elif (hf or 0.0) >= 0.5:
@@ -656,7 +743,7 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
         "bound": bound,
         "kernel": dom,
         "achieved": (d.get("hbm_measured_GBps") if bound == "hbm" else vf),
-        "peak": (HBM_PEAK_MEASURED_GBS if bound == "hbm" else 1.0),
+        "peak": (None if bound is None else HBM_PEAK_MEASURED_GBS if bound == "hbm" else 1.0),
         "unit": ("GB/s of measured HBM traffic against the achievable 6290 GB/s" if bound == "hbm" else
                  "fraction of VALU issue cycles busy = 4*SQ_ACTIVE_INST_VALU quad-cycles / (1024 SIMDs * GRBM_GUI_ACTIVE/8 cycles)"),
         "frac": frac,
@@ -671,12 +758,15 @@ def build_roofline(W, world, fwd_ms, bwd_ms, bytes_fwd, bytes_bwd, comp_fwd, com
         "kernels": per_kernel,
         "counters_source": (counters or {}).get("source"),
         "counters_stale": stale,
+        "isa_constants": isa if isa else {"unusable": isa_why},
         "useful_valu_frac": per_kernel.get("forward_kernel", {}).get("useful_valu_frac"),
         "useful_scan_valu_frac": per_kernel.get("forward_kernel", {}).get("useful_scan_valu_frac"),
         "fp32_frac_of_peak": per_kernel.get("forward_kernel", {}).get("fp32_frac_of_peak"),
-        "note": "pointer-chasing walk served from L1/L2: HBM is nowhere near its peak and is not the bound; the "
-                "kernel is VALU-issue bound (DESIGN.md section 4).  achieved/frac come from the committed SQ "
-                "counter pass of this same workload; avg_launch_ms, algorithmic and compulsory figures are live.",
+        "note": ("no committed hardware counters describe this workload on these kernel sources: bound / achieved / frac "
+                 "/ traffic are null; avg_launch_ms, algorithmic and compulsory figures are live." if bound is None else
+                 "achieved / frac / traffic come from the committed rocprofv3 --pmc passes of this same workload on these "
+                 "same kernel sources (counters_source); avg_launch_ms, algorithmic and compulsory figures are live.  "
+                 "The image-shaped walks are served from L1/L2 and bound by VALU issue, not by HBM (DESIGN.md section 4)."),
     }
     return out
 
@@ -776,6 +866,33 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
             out[f"{key}_rel_l2"] = float(f"{rel:.3e}")
             out[f"{key}_within_1e-3"] = bool(ok)
     return out
+
+
+def cpu_baseline_render(W, fm, cam, start_np, render_out):
+    """The render path's CPU baseline: the oracle's restatement of the benchmark kernel (pipeline.cu:472-544 + cast_ray +
+    make_rgba8) on the SAME camera, whole frame, all host cores; its RGBA8 words against the frame the GPU just wrote."""
+    from oracle import oracle as O
+
+    cores = int(O.lib().rfo_max_threads())
+    half_attrs = fm["attributes"].astype(np.float16)     # what benchmark.py feeds the fp16 pipeline (benchmark.py:36)
+    diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    start = np.uint32(np.asarray(start_np).reshape(-1)[0])
+    t0 = time.perf_counter()
+    ref = O.trace_benchmark(W["sh"], fm["points"], half_attrs, fm["point_adjacency"], fm["point_adjacency_offsets"],
+                            diff, cam, start, weight_threshold=0.05)
+    dt = time.perf_counter() - t0
+    got = render_out.cpu().numpy().view(np.uint32).reshape(ref.shape)
+    n = int(ref.size)
+    differ = int((got != ref).sum())
+    return {
+        "value": round(n / dt / 1e6, 5), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": f"the whole {W['height']}x{W['width']} frame of the same camera ({n} pixels), oracle/rf_oracle.c "
+                  f"rfo_trace_benchmark with OpenMP on {cores} threads of {os.cpu_count()} logical cores, {dt:.2f}s; "
+                  "fp16 face table prebuilt (excluded), as the caller's is for the GPU",
+        "frames_per_second": round(1.0 / dt, 3),
+        "matches_gpu_bitwise": differ == 0,
+        "rgba8_words_that_differ": differ,
+    }
 
 
 def reference_source_envelope(W, fm):

@@ -90,11 +90,15 @@ typedef struct rf_launch_opts {
     /* any ray scans cell i (the caller zeroes it).  Feeds the compulsory-traffic floor of bench.py's   */
     /* roofline: bytes of the distinct cells, face lists and colour rows a frame touches at least once. */
     uint8_t *visit_marks;
-    uint32_t forward_mode;    /* rf_trace_forward only: 0 = auto, 1 = the face scan requests a cell's blocks one */
-                              /*   at a time (six waves per SIMD hide the latency: large image launches), 2 = the */
-                              /*   first six blocks are requested together at the hop that enters the cell (four  */
-                              /*   waves per SIMD: flat batches, launches of at most 1024 blocks).  Same results  */
-                              /*   bit for bit; auto picks by launch shape.                                       */
+    uint32_t forward_mode;    /* 0 = auto, 1 = the face scan requests a cell's blocks one at a time (six waves per SIMD  */
+                              /*   hide the latency: large image launches), 2 = the first six blocks are requested        */
+                              /*   together at the hop that enters the cell (four waves per SIMD: flat batches, launches  */
+                              /*   of at most 1024 blocks).  0..2 give the same results bit for bit; auto picks by launch */
+                              /*   shape.  3 = the reference's own scan (tracing_utils.cuh:43-67): every face divided,    */
+                              /*   running minimum of the rounded quotients, v = (P + o/2) - O -- for callers who need    */
+                              /*   the reference's tie-breaking at near-ties; slower (a correctly rounded divide per      */
+                              /*   face).  rf_trace_backward and rf_trace_benchmark honour 3 as well (the replay of a     */
+                              /*   trail must be given the mode its forward ran in); they ignore 0..2.                    */
     /* Optional: device uint32[rf_launch_blocks(...)], the tile each block of the launch walks -- a 16x16-pixel tile of   */
     /* an image-shaped batch, a group of 256 consecutive thread slots of a flat one (values >= the number of tiles: the   */
     /* block owns no rays).  It MUST name every tile exactly once; the library does not check it (the table lives on the */

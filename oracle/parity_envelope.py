@@ -26,10 +26,13 @@ star's 1e-3 by itself.  A factor between two such figures compares two outliers,
 (tests/test_reference_source.py) is therefore: no more flipped rays than 1.5x the reference's own; no more rays
 beyond 1e-4 in rgba than 1.5x its own (floor 2), none beyond 3e-4; on the rays that take the same path, gradients
 within 2e-4 of the nearer of the two builds (the oracle spells its FMAs out, so it sits with the contracted build: 3e-7
-on attr_grad where the uncontracted build is 1.9e-3 away from both); overall gradients within 1e-2.  Any further
-change of the canonical arithmetic has to pass this before the goldens.
+on attr_grad where the uncontracted build is 1.9e-3 away from both); overall gradients within 3x the reference's own
+distance (2x for the quotient scan the reference writes, which the HIP kernels offer as forward_mode 3), and -- the
+north star's words taken literally -- at least 99.99 % of the rays within 1e-4 in rgba and as large a share of the
+gradient elements within 1e-3 as between the reference's own builds (check() below has the list).  Any further change of
+the canonical arithmetic has to pass this before the goldens.
 
-    python -m oracle.parity_envelope [c2] [north-star] [--stride 6] [--out profiles/r03/parity_baseline_scale.json]
+    python -m oracle.parity_envelope [c2] [north-star] [--stride 6] [--out profiles/r04/parity_baseline_scale.json]
 """
 from __future__ import annotations
 
@@ -52,6 +55,17 @@ def _rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
+def _elements_within(got, ref, rtol=1e-3):
+    """The north star's gradient tolerance taken literally, element by element (the bound of tests/helpers.grad_close:
+    rtol*|ref| + rtol*rms(ref)): (elements either side touches, those of them inside the bound)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    touched = (got != 0) | (ref != 0)
+    nz = ref[ref != 0]
+    rms = float(np.sqrt(np.mean(nz ** 2))) if nz.size else 0.0
+    inside = np.abs(got - ref) <= rtol * np.abs(ref) + rtol * rms
+    return int(touched.sum()), int((inside & touched).sum())
+
+
 def _pair(fa, fb, ba, bb, flipped_a, flipped_b):
     d = np.abs(np.asarray(fa["rgba"], np.float64) - np.asarray(fb["rgba"], np.float64)).max(axis=-1)
     rec = {
@@ -59,6 +73,9 @@ def _pair(fa, fb, ba, bb, flipped_a, flipped_b):
         "rays_drgba_gt_1e-4": int((d > 1e-4).sum()),
         "rays_drgba_gt_1e-5": int((d > 1e-5).sum()),
         "max_drgba": float(d.max()),
+        # the north star's colour tolerance, literally: rays whose four channels all agree to 1e-4
+        "rays": int(d.size),
+        "frac_rays_within_1e-4_rgba": float((d <= 1e-4).mean()),
     }
     for k in ("points_grad", "attr_grad"):
         ref = np.asarray(bb[k], np.float64)
@@ -68,6 +85,10 @@ def _pair(fa, fb, ba, bb, flipped_a, flipped_b):
         rec[k + "_rel_l2"] = float(np.linalg.norm(total) / scale)
         rec["same_path_" + k + "_rel_l2"] = float(np.linalg.norm(total - flipped) / scale)   # linearity
         rec["flipped_rays_" + k + "_rel_l2"] = float(np.linalg.norm(flipped) / scale)
+        # ... and its gradient tolerance, literally: per element, not a norm that two rays dominate
+        n, ok = _elements_within(ba[k], bb[k])
+        rec[k + "_elements_touched"] = n
+        rec[k + "_frac_elements_within_1e-3"] = float(ok / max(n, 1))
     return rec
 
 
@@ -132,10 +153,21 @@ def measure(fm, sh_degree, width=1920, height=1080, stride=6, grad_seed=11, with
 
 def check(rec):
     """The bar (module docstring): the oracle is inside the reference's own envelope.  Returns the list of violations
-    (empty = pass)."""
+    (empty = pass).
+
+    Stated literally first: the share of rays whose rgba agrees with the reference source to the north
+    star's 1e-4, and the share of gradient ELEMENTS inside its 1e-3 (tests/helpers.grad_close's bound) -- at least the
+    reference's own share between its two builds, less one part in 10^4.  Then the norms: overall gradient distance at
+    most 2x the reference's own for the scan that follows the reference's evaluation (oracle_quotient_scan == the HIP
+    instances of rf_launch_opts.forward_mode 3), 3x for the canonical divide-free scan (the default instances): it
+    decides near-ties without the quotients' rounding, so it shares fewer of them with either build of the reference
+    (40 / 101 flipped rays against 24 / 67 on the two frames) and the norm is carried by the one or two heaviest of
+    them -- 2.2x the reference's own distance on config 2, 0.4x on the north-star frame (check_frames holds the
+    two together)."""
     bad = []
     own = rec["ref_fma_vs_ref"]
-    for other in ("oracle_vs_ref", "oracle_vs_ref_fma"):
+    pairs = ["oracle_vs_ref", "oracle_vs_ref_fma"] + (["oracle_quotient_scan_vs_ref"] if "oracle_quotient_scan_vs_ref" in rec else [])
+    for other in pairs:
         o = rec[other]
         if o["rays_on_another_path"] > 1.5 * max(own["rays_on_another_path"], 8):
             bad.append((other, "rays_on_another_path", o["rays_on_another_path"], own["rays_on_another_path"]))
@@ -143,15 +175,39 @@ def check(rec):
             bad.append((other, "rays_drgba_gt_1e-4", o["rays_drgba_gt_1e-4"], own["rays_drgba_gt_1e-4"]))
         if not o["max_drgba"] < 3e-4:
             bad.append((other, "max_drgba", o["max_drgba"], 3e-4))
+        if not o["frac_rays_within_1e-4_rgba"] >= 0.9999:
+            bad.append((other, "frac_rays_within_1e-4_rgba", o["frac_rays_within_1e-4_rgba"], 0.9999))
+        for k in ("points_grad", "attr_grad"):
+            key = k + "_frac_elements_within_1e-3"
+            if not o[key] >= own[key] - 1e-4:
+                bad.append((other, key, o[key], own[key]))
     for k in ("points_grad", "attr_grad"):
         same = min(rec["oracle_vs_ref"]["same_path_" + k + "_rel_l2"],
                    rec["oracle_vs_ref_fma"]["same_path_" + k + "_rel_l2"])
         if not same < 2e-4:
             bad.append(("oracle_vs_nearer_build", "same_path_" + k + "_rel_l2", same, 2e-4))
+        floor = max(own[k + "_rel_l2"], 1e-4)    # attr_grad: the two builds agree to 1e-5 on some frames
         overall = min(rec["oracle_vs_ref"][k + "_rel_l2"], rec["oracle_vs_ref_fma"][k + "_rel_l2"])
-        if not overall < 1e-2:
-            bad.append(("oracle_vs_nearer_build", k + "_rel_l2", overall, 1e-2))
+        if not overall <= 3.0 * floor:
+            bad.append(("oracle_vs_nearer_build", k + "_rel_l2", overall, 3.0 * floor))
+        if "oracle_quotient_scan_vs_ref" in rec:
+            strict = rec["oracle_quotient_scan_vs_ref"][k + "_rel_l2"]
+            if not strict <= 2.0 * floor:
+                bad.append(("oracle_quotient_scan_vs_ref", k + "_rel_l2", strict, 2.0 * floor))
     return bad
+
+
+def check_frames(records):
+    """Across frames (a list of measure() records): the geometric mean of (canonical scan's overall points_grad distance
+    to the nearer build) / (the reference's own distance between its builds) must not exceed 1.5 -- one frame's ratio
+    compares two outliers, the mean over frames says whether the canonical scan is systematically further from the
+    reference than the reference is from itself.  Returns (ratios, violations)."""
+    ratios = []
+    for rec in records:
+        own = max(rec["ref_fma_vs_ref"]["points_grad_rel_l2"], 1e-4)
+        ratios.append(min(rec["oracle_vs_ref"]["points_grad_rel_l2"], rec["oracle_vs_ref_fma"]["points_grad_rel_l2"]) / own)
+    gm = float(np.exp(np.mean(np.log(np.maximum(ratios, 1e-12))))) if ratios else 0.0
+    return ratios, ([("canonical_over_own_geomean", gm, 1.5)] if gm > 1.5 else [])
 
 
 def load_foam(name, build_if_missing=True):
@@ -175,11 +231,13 @@ def main(argv):
         rec["violations"] = check(rec)
         result[name] = rec
         print(name, json.dumps(rec, indent=1))
+    ratios, bad = check_frames(list(result.values()))
+    print("canonical scan / reference's own overall points_grad distance per frame:", [round(r, 3) for r in ratios], bad)
     if out:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         with open(out, "w") as f:
             json.dump(result, f, indent=1)
-    return 0 if all(not r["violations"] for r in result.values()) else 1
+    return 0 if all(not r["violations"] for r in result.values()) and not bad else 1
 
 
 if __name__ == "__main__":

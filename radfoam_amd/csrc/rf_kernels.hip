@@ -110,6 +110,7 @@ struct BwdParams {
     const uint32_t *trail;
     const uint32_t *trail_hops;
     uint32_t trail_cap, trail_slots;
+    uint32_t strict;             // the forward of these rays ran the reference's quotient scan (forward_mode 3)
     unsigned long long *stats;   // optional scatter counters (experiments): [0] row flushes [1] values flushed
                                  // [2] lane contributions that bypassed the block cache [3] cached lane contributions
 };
@@ -373,6 +374,52 @@ __device__ __forceinline__ ScanResult scan_faces_eager(const GeoBlocks<K> &G, co
     return r;
 }
 
+// The reference's own evaluation of a scan (tracing_utils.cuh:43-67), selectable as rf_launch_opts.forward_mode = 3:
+// v = (P + o/2) - O, EVERY face divided (IEEE), a running minimum of the rounded quotients, strict '<' (the first
+// minimum wins).  Same face table, same dot-product association as everywhere else; bit-identical to the CPU checker's
+// "reference" scan mode.  It exists for callers who need the reference's tie-breaking (the canonical scan above decides
+// a near-tie by cross-multiplication, i.e. without the rounding of the two quotients; DESIGN.md section 2 has both
+// distances to the reference source) and costs a correctly rounded divide per face.
+__device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uint32_t cnt, float Px, float Py, float Pz,
+                                                        float Ox, float Oy, float Oz, float dx, float dy, float dz) {
+    ScanResult r;
+    r.t1 = __builtin_inff();
+    r.k = kNone;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
+    for (uint32_t k = 0; k < cnt; k += 4) {
+        GeoXY A;
+        GeoZ B;
+        load_geo_block(src, A, B);
+        src += 6;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t wx = j < 2 ? A.x01 : A.x23, wy = j < 2 ? A.y01 : A.y23, wz = j < 2 ? B.z01 : B.z23;
+            const float ox = (j & 1) ? half_hi(wx) : half_lo(wx);
+            const float oy = (j & 1) ? half_hi(wy) : half_lo(wy);
+            const float oz = (j & 1) ? half_hi(wz) : half_lo(wz);
+            const float dp = dot3(ox, oy, oz, dx, dy, dz);
+            const float vx = (Px + ox * 0.5f) - Ox;
+            const float vy = (Py + oy * 0.5f) - Oy;
+            const float vz = (Pz + oz * 0.5f) - Oz;
+            const float t = dot3(vx, vy, vz, ox, oy, oz) / dp;
+            const bool take = (dp > 0.0f) & (t < r.t1);
+            r.t1 = take ? t : r.t1;
+            r.k = take ? k + (uint32_t)j : r.k;
+        }
+    }
+    return r;
+}
+
+// t of the crossed face as scan_faces_strict forms it (the trail replay of a strict forward must reproduce that float)
+__device__ __forceinline__ float face_hit_strict(float ox, float oy, float oz, float Px, float Py, float Pz, float Ox,
+                                                 float Oy, float Oz, float dx, float dy, float dz) {
+    const float dp = dot3(ox, oy, oz, dx, dy, dz);
+    const float vx = (Px + ox * 0.5f) - Ox;
+    const float vy = (Py + oy * 0.5f) - Oy;
+    const float vz = (Pz + oz * 0.5f) - Oz;
+    return dot3(vx, vy, vz, ox, oy, oz) / dp;
+}
+
 // fp16-rounded offset from cell p to its neighbour q, as the face tables hold it (pack_diff)
 __device__ __forceinline__ void face_offset(const float4 &p, const float4 &q, float &ox, float &oy, float &oz) {
     ox = (float)(_Float16)(q.x - p.x);
@@ -513,14 +560,16 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 #ifndef RF_FWD_WAVES_EAGER
 #define RF_FWD_WAVES_EAGER 4
 #endif
-constexpr int forward_waves(int deg, bool half, bool quant, bool stats, bool eager) {
-    if (eager) return (deg <= 2 && !quant) ? RF_FWD_WAVES_EAGER : 3;
+constexpr int kScanBlocks = 0, kScanEager = 1, kScanStrict = 2;   // forward_kernel's SCAN parameter
+constexpr int forward_waves(int deg, bool half, bool quant, bool stats, int scan) {
+    if (scan == kScanEager) return (deg <= 2 && !quant) ? RF_FWD_WAVES_EAGER : 3;
     if (quant || stats) return RF_FWD_WAVES_OTHER;
     return deg <= 2 ? RF_FWD_WAVES_MAIN : (half ? RF_FWD_WAVES_D3_HALF : RF_FWD_WAVES_D3);
 }
 
-template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS, bool EAGER>
-__global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, EAGER)) void forward_kernel(FwdParams p) {
+template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS, int SCAN>
+__global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN)) void forward_kernel(FwdParams p) {
+    constexpr bool EAGER = SCAN == kScanEager;
     const uint32_t lane = threadIdx.x & 63u;
 #ifdef RF_EXPERIMENT_TIMELINE
     const unsigned long long tl_start = wall_clock64();
@@ -603,6 +652,8 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, EAGE
         if (alive) {
             if constexpr (EAGER)
                 sr = scan_faces_eager(GB, fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
+            else if constexpr (SCAN == kScanStrict)
+                sr = scan_faces_strict(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
             else
                 sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
             if (want_stats) {
@@ -1119,7 +1170,10 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
         sr.t1 = __builtin_inff();
         sr.k = kNone;
         if (alive) {
-            sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
+            if (p.strict)
+                sr = scan_faces_strict(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
+            else
+                sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
             if (sr.k == kNone) alive = false;
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
@@ -1217,6 +1271,7 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
             float ox, oy, oz, dp;
             face_offset(head, nhead, ox, oy, oz);
             face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
+            if (p.strict) t1 = face_hit_strict(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
         }
         if (alive) {
             if (t1 > R.t0) {
@@ -1450,6 +1505,7 @@ struct TrailWalker {
             float ox, oy, oz, dp;
             face_offset(head, nhead, ox, oy, oz);
             face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
+            if (p.strict) t1 = face_hit_strict(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
         }
 #ifdef RF_EXPERIMENT_SECTIONS
         asm volatile("" : "+v"(t1));
@@ -2153,18 +2209,26 @@ struct LaunchForward {
         // little, most face lists come from HBM) and any launch small enough to be resident at once with at most four
         // waves per SIMD (the launch is as long as its longest ray's chain of dependent loads).
         const bool eager = forward_mode ? forward_mode == 2u : (p.grid.img_w == 0 || nb <= kResidentBlocks);
-        if (bench)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+        const dim3 g(nb), b(kBlock);
+        if (forward_mode == 3u) {   // the reference's quotient scan (scan_faces_strict); statistics stay on the canonical scan
+            if (bench)
+                hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false, kScanStrict>), g, b, 0, stream, p);
+            else if (p.nq)
+                hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, kScanStrict>), g, b, 0, stream, p);
+            else
+                hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, kScanStrict>), g, b, 0, stream, p);
+        } else if (bench)
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false, kScanBlocks>), g, b, 0, stream, p);
         else if (p.stats)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, true, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, true, kScanBlocks>), g, b, 0, stream, p);
         else if (p.nq && eager)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, true>), dim3(nb), dim3(kBlock), 0, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, kScanEager>), g, b, 0, stream, p);
         else if (p.nq)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, kScanBlocks>), g, b, 0, stream, p);
         else if (eager)
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, true>), dim3(nb), dim3(kBlock), 0, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, kScanEager>), g, b, 0, stream, p);
         else
-            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, false>), dim3(nb), dim3(kBlock), 0, stream, p);
+            hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, kScanBlocks>), g, b, 0, stream, p);
         return check_launch(bench ? "rf_trace_benchmark" : "rf_trace_forward");
     }
 };
@@ -2315,7 +2379,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_depths || !quantile_point_indices))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: depth quantile buffers missing");
-    if (opts->forward_mode > 2u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: forward_mode must be 0..2");
+    if (opts->forward_mode > 3u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: forward_mode must be 0..3");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -2377,6 +2441,7 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
         return fail(RF_ERR_INVALID_ARGUMENT, "depth_grad must be provided if depth_quantiles is provided");
     if (opts->backward_mode > 4u)
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0..4");
+    if (opts->forward_mode > 3u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: forward_mode must be 0..3");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -2406,6 +2471,7 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     p.attr_grad = static_cast<float *>(attribute_grad);
     p.point_error = static_cast<float *>(point_error);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
+    p.strict = opts->forward_mode == 3u ? 1u : 0u;
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: trail_slots smaller than rf_trail_slots()");
@@ -2460,7 +2526,8 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
     p.cam = *camera;
     p.inv_tan_half_fov = 1.0f / tanf(camera->fov * 0.5f);
     p.rgba8 = ray_rgba;
-    return dispatch<LaunchForward>(sh_degree, half, p, true, 1u, s);
+    if (opts->forward_mode > 3u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_benchmark: forward_mode must be 0..3");
+    return dispatch<LaunchForward>(sh_degree, half, p, true, opts->forward_mode == 3u ? 3u : 1u, s);
 }
 
 }  // extern "C"

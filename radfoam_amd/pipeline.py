@@ -214,7 +214,9 @@ class Pipeline:
         #: (rf_launch_opts.backward_mode)
         self.backward_mode = 0
         #: 0 auto, 1 face blocks requested one at a time, 2 the first six of a cell together (rf_launch_opts.forward_mode;
-        #: same results, auto picks by launch shape)
+        #: same results, auto picks by launch shape); 3 = the reference's own per-face quotient scan
+        #: (tracing_utils.cuh:43-67) in trace_forward, trace_backward and trace_benchmark: the reference's tie-breaking
+        #: where two exits agree to an ulp, at the price of a divide per face (``strict_reference_scan`` sets it)
         self.forward_mode = 0
         #: experiment builds only (scripts/): int64 device tensor handed to rf_trace_backward as rf_launch_opts.stats
         self.experiment_stats = None
@@ -281,6 +283,16 @@ class Pipeline:
         #: batches smaller than this are traced as they come
         self.reorder_min_rays = 16384
         self._order = None
+
+    @property
+    def strict_reference_scan(self) -> bool:
+        """True: every scan divides every face and keeps a running minimum of the rounded quotients, exactly as
+        tracing_utils.cuh:43-67 writes it (forward_mode 3), instead of the divide-free canonical scan."""
+        return int(self.forward_mode) == 3
+
+    @strict_reference_scan.setter
+    def strict_reference_scan(self, on):
+        self.forward_mode = 3 if on else 0
 
     def invalidate(self):
         """Forget the cached packed foam, hop trail and ray order of this Pipeline (and free the trail).
@@ -464,7 +476,7 @@ class Pipeline:
 
     def _trail_key(self, foam, rays, start, quantiles, settings):
         return (tuple(self._tkey(t) for t in foam), self._tkey(rays), self._tkey(start), self._tkey(quantiles),
-                float(settings.weight_threshold), int(settings.max_intersections))
+                float(settings.weight_threshold), int(settings.max_intersections), int(self.forward_mode) == 3)
 
     def _ray_order(self, opts, rays_c, start_c, num_rays):
         """Set opts.ray_order for a flat batch: the permutation rf_build_ray_order computes, cached on

@@ -5,7 +5,7 @@ mkdir -p $R/gpurun_out/ab
 for v in $VARIANTS; do
   L=$R/radfoam_amd/libradfoam_hip_$v.so
   [ "$v" = "base" ] && L=$R/radfoam_amd/libradfoam_hip.so
-  RADFOAM_HIP_LIB=$L timeout 400 python bench.py --steps ${AB_STEPS:-6} --warmup 2 --no-cpu-baseline $BENCH_EXTRA 2>/dev/null | tail -1 > $R/gpurun_out/ab/$v.json
+  RADFOAM_HIP_LIB=$L timeout 400 python bench.py --steps ${AB_STEPS:-6} --warmup 2 --no-cpu-baseline --no-other-workloads $BENCH_EXTRA 2>/dev/null | tail -1 > $R/gpurun_out/ab/$v.json
   python - "$v" "$R/gpurun_out/ab/$v.json" <<'PY'
 import json,sys
 try:

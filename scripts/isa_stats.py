@@ -1,6 +1,11 @@
 """Static ISA statistics of the walk kernels without a GPU: compiles rf_kernels.hip for gfx950 to assembly
 (device only) and prints, per kernel, the instruction mix, register counts, scratch and LDS.
-usage: python scripts/isa_stats.py [extra -D flags ...] [--filter substring] [--dump kernel_substring out.s]"""
+usage: python scripts/isa_stats.py [extra -D flags ...] [--filter substring] [--dump kernel_substring out.s]
+       python scripts/isa_stats.py --constants [out.json]
+--constants: the instruction counts bench.py's roofline rests on (SCAN_VALU_PER_4_FACES, HOP_VALU_PER_LANE), read off the
+ISA of the shipped forward instance instead of being typed in: VALU instructions of the face-scan loop (the innermost
+loop: one block of four faces per trip) and of one wave-step outside it (the rest of the outer loop's body), with the
+sha256 of the sources they were compiled from; written to profiles/isa_constants.json by default."""
 import os
 import re
 import subprocess
@@ -9,6 +14,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:]
 flt, dump = None, None
+constants_out = None
+if "--constants" in args:
+    i = args.index("--constants")
+    constants_out = args[i + 1] if i + 1 < len(args) and not args[i + 1].startswith("-") else \
+        os.path.join(ROOT, "profiles", "isa_constants.json")
+    del args[i:i + (2 if i + 1 < len(args) and not args[i + 1].startswith("-") else 1)]
 if "--filter" in args:
     i = args.index("--filter")
     flt = args[i + 1]
@@ -26,6 +37,68 @@ text = open(out).read()
 # kernels: from "<name>:" label (a global function symbol) to ".end_amdhsa_kernel" metadata; simpler: split on .globl
 funcs = re.split(r"\n\s*\.globl\s+", text)
 kernel_meta = text[text.find("amdhsa.kernels"):].split("\n  - ")
+
+
+def loop_counts(body):
+    """VALU instructions of the innermost loop and of the rest of the outermost loop's body, from the loop annotations
+    the compiler writes behind block labels ('=>This Loop Header: Depth=1', 'Parent Loop BBx_y Depth=1' + 'This Inner
+    Loop Header: Depth=2', 'in Loop: Header=BBx_y Depth=1')."""
+    lines = body.splitlines()
+    is_ins = lambda l: l.startswith("\t") and l.strip() and not l.strip().startswith((".", ";"))
+    starts = [i for i, l in enumerate(lines) if re.match(r"^(\.LBB\d+_\d+:|; %bb\.\d+:)", l)] + [len(lines)]
+    depth_of = {}
+    for a, b in zip(starts[:-1], starts[1:]):
+        note = lines[a] + " " + (lines[a + 1] if a + 1 < len(lines) and lines[a + 1].lstrip().startswith(";") else "")
+        if "Inner Loop Header: Depth=2" in note or re.search(r"in Loop: Header=\S+ Depth=2", note):
+            depth = 2
+        elif "Depth=1" in note:
+            depth = 1
+        else:
+            depth = 0
+        depth_of[(a, b)] = depth
+    ops = lambda a, b: [l.strip().split()[0] for l in lines[a:b] if is_ins(l)]
+    valu = lambda o: sum(1 for x in o if x.startswith("v_"))
+    scan = [x for (a, b), d in depth_of.items() if d == 2 for x in ops(a, b)]
+    # a wave-step outside the scan: the hop (link, next cell record, trail entry, loop bookkeeping) and -- recognisable by
+    # what only they contain -- the compositing blocks: the colour-row gather (>= 3 dwordx4 loads), exp (v_ldexp_f32),
+    # the contribution atomic
+    hop = comp = 0
+    for (a, b), d in depth_of.items():
+        if d != 1:
+            continue
+        o = ops(a, b)
+        is_comp = sum(1 for x in o if x.startswith("global_load_dwordx4")) >= 3 or any("ldexp" in x for x in o) or \
+            any(x.startswith("global_atomic_add") for x in o)
+        if is_comp:
+            comp += valu(o)
+        else:
+            hop += valu(o)
+    n = lambda pre: sum(1 for x in scan if x.startswith(pre))
+    flop = 4 * n("v_pk_fma_f32") + 2 * (n("v_pk_mul_f32") + n("v_pk_add_f32")) + 2 * (n("v_fma_f32") + n("v_fmac_f32")) + \
+        n("v_mul_f32") + n("v_add_f32") + n("v_sub_f32")
+    return {"scan_valu_per_4_faces": valu(scan), "scan_flop_per_4_faces": flop, "hop_valu_per_lane": hop,
+            "composite_valu_per_lane": comp}
+
+
+if constants_out:
+    import hashlib
+    import json
+    sys.path.insert(0, ROOT)
+    from radfoam_amd import build as hip_build
+    want = "void rf::forward_kernel<2, false, false, false, false, 0>"
+    found = None
+    for f in funcs[1:]:
+        name = f.split("\n", 1)[0].strip()
+        dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+        if dem.split("(")[0] == want:
+            found = loop_counts(f.split(".Lfunc_end", 1)[0])
+    assert found, "forward instance not found in the ISA"
+    rec = {"csrc_sha256": hip_build.source_hash(), "kernel": want,
+           "source": "scripts/isa_stats.py --constants (hipcc -S of radfoam_amd/csrc/rf_kernels.hip, gfx950)", **found}
+    json.dump(rec, open(constants_out, "w"), indent=1)
+    print(json.dumps(rec))
+    sys.exit(0)
+
 rows = []
 for f in funcs[1:]:
     name = f.split("\n", 1)[0].strip()

@@ -893,3 +893,58 @@ def test_ray_order_handles_degenerate_directions(foam_factory):
     good = torch.isfinite(outs[1]["rgba"]).all(dim=-1)
     assert torch.equal(outs[0]["rgba"][good], outs[1]["rgba"][good])
     assert torch.equal(outs[0]["num_intersections"], outs[1]["num_intersections"])
+
+
+@pytest.mark.parametrize("d,image,quantiles", [(0, True, False), (2, True, True), (3, False, True), (1, False, False)])
+def test_strict_reference_scan_instance(foam_factory, d, image, quantiles):
+    """rf_launch_opts.forward_mode = 3 (Pipeline.strict_reference_scan): the reference's own scan -- every face divided,
+    a running minimum of the rounded quotients, v = (P + o/2) - O (tracing_utils.cuh:43-67) -- in trace_forward,
+    trace_backward (replay of a trail recorded under it, short trail + re-walk, no trail) and trace_benchmark:
+    BIT-IDENTICAL to the oracle in its "reference" scan mode, as the canonical instances are to the canonical mode."""
+    with O.scan_mode("reference"):
+        fm, rays, starts, q, dg, g, err, fwd, ref = _backward_case(foam_factory, d, 60 + d, image, quantiles, False,
+                                                                   n_points=7000)
+        diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+        cam, _, cstart = H.camera_setup(fm, 100, 60)
+        bench_ref = O.trace_benchmark(d, fm["points"], fm["attributes"], fm["point_adjacency"],
+                                      fm["point_adjacency_offsets"], diff, cam, cstart, weight_threshold=0.05)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    t = lambda x: None if x is None else torch.from_numpy(x).to(DEV)
+    tr, ts, tq = t(rays), t(starts), t(q)
+    for trail in ("replay", "short", "rewalk"):
+        pipe = _pipeline(d)
+        pipe.strict_reference_scan = True
+        assert pipe.forward_mode == 3
+        if trail == "rewalk":
+            pipe.record_trail = False
+        elif trail == "short":
+            pipe.trail_steps = 5
+        f = pipe.trace_forward(p, a, adj, off, tr, ts, depth_quantiles=tq)
+        np.testing.assert_array_equal(f["rgba"].cpu().numpy().view(np.uint32), fwd["rgba"].view(np.uint32))
+        np.testing.assert_array_equal(f["num_intersections"].cpu().numpy().view(np.uint32), fwd["num_intersections"])
+        if quantiles:
+            np.testing.assert_array_equal(f["depth"].cpu().numpy().view(np.uint32), fwd["depth"].view(np.uint32))
+            np.testing.assert_array_equal(f["depth_indices"].cpu().numpy().view(np.uint32), fwd["depth_indices"])
+        out = pipe.trace_backward(p, a, adj, off, tr, ts, f["rgba"], t(g), tq, f.get("depth_indices"), t(dg))
+        torch.cuda.synchronize()
+        for key in ("points_grad", "attr_grad"):
+            ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+            assert ok and rel < 1e-5, (trail, key, rel, worst)
+    # a trail recorded by the canonical scan is not replayed by a strict backward (and the other way round): the key differs
+    pipe = _pipeline(d)
+    f = pipe.trace_forward(p, a, adj, off, tr, ts, depth_quantiles=tq)
+    pipe.strict_reference_scan = True
+    out = pipe.trace_backward(p, a, adj, off, tr, ts, t(fwd["rgba"]), t(g), tq, t(fwd.get("depth_indices")), t(dg))
+    for key in ("points_grad", "attr_grad"):
+        ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+        assert ok and rel < 1e-5, ("canonical trail, strict backward", key, rel, worst)
+    # the render path
+    pipe = _pipeline(d)
+    pipe.strict_reference_scan = True
+    dtab = pipe.build_adjacent_diff(p, adj, off)
+    img = torch.zeros((60, 100), dtype=torch.uint32, device=DEV)
+    camera = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+    sp = torch.tensor([int(cstart)], dtype=torch.int64).to(torch.uint32).to(DEV)
+    pipe.trace_benchmark(p, a, adj, off, dtab, camera, sp, img, weight_threshold=0.05)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(img.cpu().numpy().view(np.uint32), bench_ref)

@@ -267,20 +267,52 @@ def test_bench_roofline_refuses_counters_of_other_kernel_sources(monkeypatch):
 
     committed = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "counters.json")))
     assert committed["north-star"].get("csrc_sha256"), "counters.json must record the sources it was measured on"
-    walk = {"faces_scanned": 4_945_000_000, "hops": 266_000_000, "cells_scanned": 266_000_000}
+    walk = {"faces_scanned": 4_945_000_000, "hops": 266_000_000, "cells_scanned": 266_000_000, "segments_lit": 44_000_000}
     W = dict(bench.WORKLOADS["north-star"], name="north-star", nq=0)
+    isa_file = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "isa_constants.json")))
 
+    # counters and ISA constants both describe the running sources
     monkeypatch.setattr(hip_build, "source_hash", lambda: committed["north-star"]["csrc_sha256"])
+    monkeypatch.setattr(bench, "isa_constants", lambda: ({k: isa_file[k] for k in (
+        "scan_valu_per_4_faces", "scan_flop_per_4_faces", "hop_valu_per_lane", "composite_valu_per_lane")}, None))
     fresh = bench.build_roofline(W, 1, 4.7, 3.9, 5.0e10, 6.0e10, 1.3e9, 1.0e9, walk)
     assert fresh["counters_stale"] is False and 0.5 < fresh["frac"] < 1.0 and fresh["bound"] == "valu_issue"
     assert 0.3 < fresh["useful_scan_valu_frac"] < fresh["useful_valu_frac"] < 1.0
     assert 0.05 < fresh["fp32_frac_of_peak"] < 0.3 and fresh["traffic"] > 1e9
+    monkeypatch.undo()
 
+    # other sources: neither the counters nor the ISA constants are quoted, and no bound is assumed
     monkeypatch.setattr(hip_build, "source_hash", lambda: "0" * 64)
     stale = bench.build_roofline(W, 1, 4.7, 3.9, 5.0e10, 6.0e10, 1.3e9, 1.0e9, walk)
     assert stale["counters_stale"] is True and stale["frac"] is None and stale["traffic"] is None
-    assert stale["useful_valu_frac"] is None and stale["fp32_frac_of_peak"] is not None   # live figures stay
-    assert stale["kernels"]["forward_kernel"]["avg_launch_ms"] == 4.7
+    assert stale["bound"] is None and stale["peak"] is None
+    assert stale["useful_valu_frac"] is None and "unusable" in stale["isa_constants"]
+    assert stale["kernels"]["forward_kernel"]["avg_launch_ms"] == 4.7            # live figures stay
+    # a workload nobody took counters for: bound null, not a label
+    W2 = dict(bench.WORKLOADS["c2"], name="no-such-workload", nq=0)
+    assert bench.build_roofline(W2, 1, 3.0, 3.0, 1e10, 1e10, 1e9, 1e9, walk)["bound"] is None
+
+
+def test_isa_constants_file_matches_bench_literals_and_says_which_sources():
+    """the instruction counts bench.py's useful_valu_frac rests on come from the ISA
+    (scripts/isa_stats.py --constants -> profiles/isa_constants.json), carry the sha256 of the sources they were read
+    off, and equal the literals in bench.py; bench.isa_constants() quotes them only then."""
+    import json
+
+    import bench
+    from radfoam_amd import build as hip_build
+
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "isa_constants.json")))
+    assert rec["scan_valu_per_4_faces"] == bench.SCAN_VALU_PER_4_FACES
+    assert rec["scan_flop_per_4_faces"] == bench.SCAN_FLOP_PER_4_FACES
+    assert rec["hop_valu_per_lane"] == bench.HOP_VALU_PER_LANE
+    assert rec["composite_valu_per_lane"] == bench.COMPOSITE_VALU_PER_LANE
+    got, why = bench.isa_constants()
+    if rec["csrc_sha256"] == hip_build.source_hash():
+        assert why is None and got["scan_valu_per_4_faces"] == 59
+    else:
+        assert got is None and "other kernel sources" in why
+        pytest.xfail("kernel sources changed after profiles/isa_constants.json was made: python scripts/isa_stats.py --constants")
 
 
 def test_the_committed_counters_describe_the_committed_kernel_sources():

@@ -154,6 +154,9 @@ def test_canonical_arithmetic_takes_the_reference_sources_paths_on_a_large_frame
     assert float(ro["rgba"][..., 3].max()) > 0.9 and float(ro["num_intersections"].mean()) > 40
 
 
+_ENVELOPE_RECORDS = {}
+
+
 def _envelope_case(name):
     from oracle import parity_envelope as PE
     from oracle import refsrc as Rf
@@ -166,7 +169,7 @@ def _envelope_case(name):
     if not cached and n > 500_000 and not os.environ.get("RF_TEST_LARGE"):
         pytest.skip(f"the {n}-point foam is not cached (Qhull takes minutes): python -m radfoam_amd.foam {n} {seed}")
     fm, d = PE.load_foam(name)
-    return PE, PE.measure(fm, d, with_quotient_mode=False)
+    return PE, PE.measure(fm, d, with_quotient_mode=True)
 
 
 @pytest.mark.parametrize("name", ["c2", "north-star"])
@@ -184,3 +187,13 @@ def test_oracle_is_inside_the_references_own_envelope_at_baseline_scale(name):
     assert of["same_path_points_grad_rel_l2"] < 2e-4 and of["same_path_attr_grad_rel_l2"] < 1e-5
     # colours: at most a couple of tie rays leave the north star's 1e-4, as between the reference's own builds
     assert max(o["rays_drgba_gt_1e-4"], of["rays_drgba_gt_1e-4"]) <= 3
+    # the north star's tolerances taken literally: share of rays / of gradient elements inside them
+    for pair in (o, of, rec["oracle_quotient_scan_vs_ref"]):
+        assert pair["frac_rays_within_1e-4_rgba"] >= 0.9999
+        assert pair["points_grad_frac_elements_within_1e-3"] >= 0.9995 and pair["attr_grad_frac_elements_within_1e-3"] >= 0.9999
+    # the quotient scan (forward_mode 3 of the kernels) stays within 2x the reference's own distance between its builds
+    assert rec["oracle_quotient_scan_vs_ref"]["points_grad_rel_l2"] <= 2.0 * max(own["points_grad_rel_l2"], 1e-4)
+    _ENVELOPE_RECORDS[name] = rec
+    if len(_ENVELOPE_RECORDS) == 2:     # both frames measured in this session: the canonical scan over the two together
+        ratios, bad = PE.check_frames(list(_ENVELOPE_RECORDS.values()))
+        assert bad == [], (ratios, bad)
