@@ -101,13 +101,17 @@ WORKLOADS = {
                         rays=1_000_000, label="stand-in for BASELINE config 4 (training batch)"),
     "render": dict(points=1_000_000, seed=2, sh=3, width=1557, height=1038, forward_only=True, kind="render",
                    label="stand-in for BASELINE config 3 (benchmark.py render path)"),
+    # BASELINE config 4 as a LOOP: the reference's unmodified RadFoamScene driven as train.py:162-270 drives it
+    # (examples/train_loop.py); --steps = iterations (default 300), value = iterations per second
+    "train-loop": dict(points=2_000_000, seed=5, sh=3, width=1920, height=1080, forward_only=False, kind="loop",
+                       rays=1_000_000, label="stand-in for BASELINE config 4 (full training loop)"),
 }
 
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; train-loop: 300 iterations)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="north-star")
     ap.add_argument("--points", type=int, default=None)
@@ -125,12 +129,20 @@ def parse_args(argv=None):
     ap.add_argument("--no-rebalance", action="store_true", help="N>1: keep the even row split")
     ap.add_argument("--tile-order", default=None,
                     help="image workloads: Pipeline.tile_order_mode (default: the pipeline's own)")
+    ap.add_argument("--empty-density", type=float, default=None,
+                    help="raise the foam's zero densities to this value (4.5e-6 = activation_scale * softplus(-1, beta=10), "
+                         "what the reference's scene gives its empty cells, scene.py:459): every segment is then 'lit' "
+                         "(> 1e-6), as in real training, where softplus never returns exactly 0")
+    ap.add_argument("--grad-pitch", default=None, help="Pipeline.gradient_row_pitch: auto (default), dense, or floats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default line only: skip the untimed `other_workloads` record (c2, c5, render, train-batch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: CPU test of the launcher)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 300 if args.workload == "train-loop" else 10
+    return args
 
 
 def resolve_workload(args):
@@ -273,7 +285,7 @@ def main():
 
     env = dict(torch=torch, dist=dist, world=world, rank=rank, dev=dev, on_gpu=on_gpu, test_factory=test_factory)
     W = resolve_workload(args)
-    result = run_workload(args, W, env)
+    result = run_train_loop(args, W, env) if W["kind"] == "loop" else run_workload(args, W, env)
     if result is not None and on_gpu and world == 1 and args.workload == "north-star" and not W.get("custom") and \
             not args.forward_only and not args.quantiles and not args.no_other_workloads and not args.no_cpu_baseline:
         # the driver runs this file once, with no flags -- so that one run also observes the other
@@ -284,6 +296,49 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_train_loop(args, W, env):
+    """--workload train-loop: examples/train_loop.py (one GPU; the loop is the reference's, which has no data-parallel
+    mode).  One JSON line in the same shape as the others; `value` is iterations per second."""
+    if env["world"] != 1 or not env["on_gpu"]:
+        raise SystemExit("--workload train-loop runs on one GPU")
+    torch, dev = env["torch"], env["dev"]
+    from examples import train_loop
+    from radfoam_amd import foam
+
+    def gpu_triangulation(raw):
+        from radfoam_amd import triangulation
+        _, sorted_pts = triangulation.kd_order(torch.from_numpy(raw).to(dev))
+        adj, off, _ = triangulation.delaunay_adjacency(sorted_pts)
+        return sorted_pts.cpu().numpy(), off.cpu().numpy(), adj.cpu().numpy()
+
+    t0 = time.time()
+    fm = foam.make_synthetic_foam(W["points"], W["sh"], W["seed"], cache_dir=foam.default_cache_dir(),
+                                  triangulate=gpu_triangulation)
+    its, detail = train_loop.run(args, env, fm, sh_degree=W["sh"], iterations=args.steps, rays_per_batch=W["rays"],
+                                 width=W["width"], height=W["height"], densify_at=max(1, args.steps // 2))
+    detail["setup_and_loop_seconds"] = round(time.time() - t0, 1)
+    per = detail["ms_per_iteration"]
+    tracer = per["tracer_forward"] + per["tracer_backward"]
+    detail["tracer_share_of_wall"] = round(tracer / detail["wall_ms_per_iteration"], 4)
+    return {
+        "metric": f"training iterations/s, {W['label']}",
+        "value": round(its, 3), "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": 0,
+        "ms_per_step": detail["wall_ms_per_iteration"], "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{W['label']}: the reference's unmodified RadFoamScene + TraceRays (radfoam_model/scene.py, "
+                        f"render.py) on a synthetic {W['points']}-point foam (seed {W['seed']}), SH degree {W['sh']}, "
+                        f"{W['rays']}-ray shuffled batches from 8 synthetic 1080p views, 2 depth quantiles per ray, Adam, "
+                        f"update_triangulation on the schedule of train.py:243-248, one densification at iteration "
+                        f"{max(1, args.steps // 2)} (collect_error_map + prune_and_densify + full rebuild)",
+            "num_points": W["points"], "sh_degree": W["sh"], "rays_per_step": W["rays"],
+            "weight_threshold": 1e-3, "max_intersections": 1024, "parallelism": "1 GPU",
+        },
+        "mrays_per_second_through_the_loop": round(its * W["rays"] / 1e6, 2),
+        "detail": detail,
+    }
 
 
 OTHER_WORKLOADS = ("c2", "c5", "render", "train-batch")
@@ -354,6 +409,12 @@ def run_workload(args, W, env):
     if world > 1 and rank == 0:
         dist.barrier()
     attr_dtype = torch.float16 if W["kind"] == "render" else torch.float32
+    if args.empty_density is not None:
+        fm = dict(fm)
+        fm["attributes"] = fm["attributes"].copy()
+        fm["attributes"][:, -1] = np.maximum(fm["attributes"][:, -1], np.float32(args.empty_density))
+        W["custom"] = True
+        W["label"] += f", empty cells at density {args.empty_density:g} (every segment lit)"
     cam = None
     if W["kind"] == "batch":
         rays_np, start_np = training_batch(fm, W["rays"], W["seed"] + 100)
@@ -385,6 +446,8 @@ def run_workload(args, W, env):
         pipe.record_trail = not W["forward_only"]   # trace_backward is driven by hand on plain tensors
         if args.tile_order is not None:
             pipe.tile_order_mode = None if args.tile_order == "static" else args.tile_order
+        if args.grad_pitch is not None:
+            pipe.gradient_row_pitch = args.grad_pitch if args.grad_pitch in ("auto", "dense") else int(args.grad_pitch)
     else:
         mod, fn = test_factory.split(":")
         pipe = getattr(importlib.import_module(mod), fn)(sh_degree)

@@ -112,6 +112,13 @@ typedef struct rf_launch_opts {
     /* tile t's longest ray.  The caller zeroes it.  What a tile_order for the next launches over the same rays is built  */
     /* from.                                                                                                            */
     uint32_t *tile_cost;
+    /* rf_trace_backward, optional: floats between two rows of attribute_grad (0 = the attribute dimension A, i.e. the     */
+    /* reference's dense [N][A] layout).  A gradient row leaves the kernels as ONE atomic instruction whose lanes are    */
+    /* the row's columns, and the memory side works per (instruction, 64-byte line): rows of A = 13 / 28 / 49 floats      */
+    /* start at every 4-byte offset and span 1.75 / 2.6 / 3.9 lines on average; with a pitch of 16 / 32 / 64 floats and a */
+    /* 64-byte aligned buffer they span 1 / 2 / 3 -- up to a quarter fewer requests for a backward that is bound by them  */
+    /* (flat batches whose every segment is lit).  Columns A .. pitch-1 are never written.                                */
+    uint32_t attr_grad_pitch;
 } rf_launch_opts;
 
 /* Last error message of the calling thread ("" if none). */
@@ -261,6 +268,14 @@ int rf_nearest_point_tree(const float *points, uint32_t num_points, const float 
 int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_t *point_adjacency,
                          const uint32_t *point_adjacency_offsets, uint32_t *indices,
                          float *cell_radius, void *stream);
+
+/* radfoam.BatchFetcher(data, batch_size, shuffle).next() for a DEVICE-resident array (torch_bindings.cpp:77-83 over
+ * src/utils/batch_fetcher.cpp:60-77): out[j] = data[index(batch_index * batch_size + j)], rows of stride_bytes (a multiple
+ * of 4); index = randint(make_rng(seq), 0, num_elements) of src/utils/random.h:13-57 when shuffle, seq % num_elements
+ * otherwise -- the reference's sequence, so fetchers over rays / colours / alphas stay aligned.  num_elements < 2^32
+ * (the reference's "Too many elements").  The reference gathers on a host thread and uploads; here the set stays in HBM. */
+int rf_fetch_batch(const void *data, uint64_t num_elements, uint32_t stride_bytes, uint32_t batch_index,
+                   uint32_t batch_size, int shuffle, void *out, void *stream);
 
 /* Coherent processing order for a flat batch of rays: sorts the ray indices by (entry cell, Morton
  * code of the direction on a 2^16 x 2^16 octahedral grid), so that 64 / 256 consecutive entries are

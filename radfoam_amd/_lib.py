@@ -60,6 +60,7 @@ class LaunchOpts(C.Structure):
         ("forward_mode", C.c_uint32),
         ("tile_order", C.c_void_p),
         ("tile_cost", C.c_void_p),
+        ("attr_grad_pitch", C.c_uint32),
     ]
 
 
@@ -86,6 +87,7 @@ SYMBOLS = {
     "rf_nearest_point": (_INT, [_P, _U32, _P, _U32, _P, _P, _P]),
     "rf_nearest_point_tree": (_INT, [_P, _U32, _P, _P, _U32, _P, _P]),
     "rf_farthest_neighbor": (_INT, [_P, _U32, _P, _P, _P, _P, _P]),
+    "rf_fetch_batch": (_INT, [_P, C.c_uint64, _U32, _U32, _U32, _INT, _P, _P]),
     "rf_ray_order_workspace_bytes": (C.c_size_t, [_U32]),
     "rf_build_ray_order": (_INT, [_P, _P, _U32, _P, _P, C.c_size_t, _P]),
     "rf_adjacency_workspace_bytes": (C.c_size_t, [_U32]),

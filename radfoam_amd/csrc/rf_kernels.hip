@@ -111,6 +111,7 @@ struct BwdParams {
     const uint32_t *trail_hops;
     uint32_t trail_cap, trail_slots;
     uint32_t strict;             // the forward of these rays ran the reference's quotient scan (forward_mode 3)
+    uint32_t attr_pitch;         // floats between two rows of attr_grad (>= A; rf_launch_opts.attr_grad_pitch)
     unsigned long long *stats;   // optional scatter counters (experiments): [0] row flushes [1] values flushed
                                  // [2] lane contributions that bypassed the block cache [3] cached lane contributions
 };
@@ -826,7 +827,7 @@ __device__ __forceinline__ void scatter_step(uint32_t lane, bool has, bool row, 
                                              const float (&sh)[sh_dim(DEG)], float dLr, float dLg,
                                              float dLb, float dL_ds, bool pg_on, uint32_t prev,
                                              float pgx, float pgy, float pgz, float *attr_grad,
-                                             float *points_grad) {
+                                             float *points_grad, uint32_t pitch) {
     constexpr int NB = sh_dim(DEG);
     constexpr int A = 1 + 3 * NB;
     if constexpr (MODE == 1) {
@@ -837,7 +838,7 @@ __device__ __forceinline__ void scatter_step(uint32_t lane, bool has, bool row, 
                 grad_add(pg + 1, pgy);
                 grad_add(pg + 2, pgz);
             }
-            float *dst = attr_grad + (size_t)cur * A;
+            float *dst = attr_grad + (size_t)cur * pitch;
             if (row) add_row_per_lane<NB>(dst, sh, dLr, dLg, dLb);
             grad_add(dst + (A - 1), dL_ds);
         }
@@ -854,7 +855,7 @@ __device__ __forceinline__ void scatter_step(uint32_t lane, bool has, bool row, 
             const uint64_t same = ballot(mine);
             if (__builtin_popcountll(same) <= 2) {
                 // (almost) nothing to share: the lanes add their own rows
-                if (mine) add_row_per_lane<NB>(attr_grad + (size_t)cur * A, sh, dLr, dLg, dLb);
+                if (mine) add_row_per_lane<NB>(attr_grad + (size_t)cur * pitch, sh, dLr, dLg, dLb);
             } else {
                 // the point gradient rides along when the whole group flushes to the same cell
                 const uint32_t pl = readlane(prev, leader);
@@ -876,7 +877,7 @@ __device__ __forceinline__ void scatter_step(uint32_t lane, bool has, bool row, 
                 for (int i = A + 3; i < NV; ++i) v[i] = 0.0f;
                 const float tot = transpose_reduce<NV>(v, lane);
                 if (lane < (uint32_t)A) {
-                    grad_add(attr_grad + (size_t)c * A + lane, tot);
+                    grad_add(attr_grad + (size_t)c * pitch + lane, tot);
                 } else if (lane < (uint32_t)(A + 3) && any_pg) {
                     grad_add(points_grad + 3 * (size_t)pl + (lane - (uint32_t)A), tot);
                 }
@@ -893,7 +894,7 @@ __device__ __forceinline__ void scatter_step(uint32_t lane, bool has, bool row, 
             const bool mine = ds_left && cur == c;
             const uint64_t same = ballot(mine);
             const float tot = wave_sum(mine ? dL_ds : 0.0f);
-            if ((int)lane == leader) grad_add(attr_grad + (size_t)c * A + (A - 1), tot);
+            if ((int)lane == leader) grad_add(attr_grad + (size_t)c * pitch + (A - 1), tot);
             todo &= ~same;
         }
         // ---- point gradients that did not ride along
@@ -1115,7 +1116,7 @@ __device__ __forceinline__ void scatter_pending(const BwdParams &p, uint32_t lan
 #endif
     if (ballot(G.has) != 0ull) {
         scatter_step<DEG, MODE>(lane, G.has, G.row, G.cur, sh, G.dLr, G.dLg, G.dLb, G.dL_ds, G.pg_on, G.prev,
-                                G.px, G.py, G.pz, p.attr_grad, p.points_grad);
+                                G.px, G.py, G.pz, p.attr_grad, p.points_grad, p.attr_pitch);
     }
     G.has = false;
     G.row = false;
@@ -1347,6 +1348,12 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 #ifndef RF_DIRECT_WAVES_D3
 #define RF_DIRECT_WAVES_D3 3
 #endif
+#ifndef RF_MERGE_ROWS
+#define RF_MERGE_ROWS 1
+#endif
+#ifndef RF_ROWS_FROM_BASIS
+#define RF_ROWS_FROM_BASIS 1
+#endif
 constexpr int kCacheProbes = RF_CACHE_PROBES;
 constexpr uint32_t kEpoch = RF_CACHE_EPOCH;
 
@@ -1394,7 +1401,7 @@ __device__ __forceinline__ int cache_find(uint32_t *keys, uint32_t key) {
 
 template <int NB>
 __device__ __forceinline__ void cache_flush(double *rows, uint32_t *keys, uint8_t *touch, bool all,
-                                              float *attr_grad, float *points_grad) {
+                                              float *attr_grad, float *points_grad, uint32_t pitch) {
     using L = CacheLayout<NB>;
     constexpr int A = 1 + 3 * NB;
     const uint32_t lane = threadIdx.x & 63u, col0 = threadIdx.x & 31u, base = threadIdx.x & ~63u;
@@ -1423,8 +1430,8 @@ __device__ __forceinline__ void cache_flush(double *rows, uint32_t *keys, uint8_
                 if (v != 0.0f) {
                     *cell = 0.0;
                     float *dst;
-                    if (col < (uint32_t)L::NCOEF) dst = attr_grad + (size_t)key * A + col;
-                    else if (col == (uint32_t)L::COL_DS) dst = attr_grad + (size_t)key * A + (A - 1);
+                    if (col < (uint32_t)L::NCOEF) dst = attr_grad + (size_t)key * pitch + col;
+                    else if (col == (uint32_t)L::COL_DS) dst = attr_grad + (size_t)key * pitch + (A - 1);
                     else dst = points_grad + 3 * (size_t)key + (col - (uint32_t)L::COL_PG);
                     grad_add(dst, v);
                 }
@@ -1598,7 +1605,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
                             for (int k = 0; k < 3 * NB; ++k) atomicAdd(row + k, (double)v[k]);
                         }
                     } else if (act) {
-                        float *dst = p.attr_grad + (size_t)G.cur * A;
+                        float *dst = p.attr_grad + (size_t)G.cur * p.attr_pitch;
 #pragma unroll
                         for (int k = 0; k < A; ++k)
                             if (v[k] != 0.0f) grad_add(dst + k, v[k]);
@@ -1609,7 +1616,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
                         s_touch[s_row] = (uint8_t)1;
                         atomicAdd(s_rows + s_row * STRIDE + L::COL_DS, (double)G.dL_ds);
                     } else if (act) {
-                        grad_add(p.attr_grad + (size_t)G.cur * A + (A - 1), G.dL_ds);
+                        grad_add(p.attr_grad + (size_t)G.cur * p.attr_pitch + (A - 1), G.dL_ds);
                     }
                 }
                 const bool pact = G.has && G.pg_on;
@@ -1642,7 +1649,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
             const unsigned long long f0 = __builtin_readcyclecounter();
 #endif
             block_alive = __syncthreads_or(W.alive ? 1 : 0) != 0;
-            cache_flush<NB>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad);
+            cache_flush<NB>(s_rows, s_keys, s_touch, !block_alive, p.attr_grad, p.points_grad, p.attr_pitch);
             __syncthreads();
 #ifdef RF_EXPERIMENT_SECTIONS
             sec_flush += __builtin_readcyclecounter() - f0;
@@ -1716,9 +1723,15 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
     // block: with the density table two blocks fit a CU (2 waves/SIMD, and every cell gather of a sparse batch
     // is its own cache miss to hide).  Staging one half-wave after the other halves that (4 blocks per CU).
     constexpr int STAGE_LANES = DEG >= 2 ? RF_STAGE_LANES_D3 : 64;   // 64, 32 or 16
-    __shared__ __attribute__((aligned(16))) float s_stage[(kBlock / 64) * STAGE_LANES * PITCH];
+    // Rows wider than a half-wave (SH degree 3: 48 columns) are not staged at all: a gradient row is the outer product
+    // basis(ray) x dL/drgb, and the ray's basis never changes -- every lane leaves its NB basis values in LDS ONCE, and
+    // the lanes that emit a row (one per column) rebuild it from there and from three wave-broadcast scalars.  No
+    // per-step staging writes, 16 KB instead of 24 KB per block, and the rows of ALL 64 lanes can be merged by cell.
+    constexpr bool FROM_BASIS = (RF_ROWS_FROM_BASIS != 0) && NC > 32;
+    constexpr int STAGE_FLOATS = FROM_BASIS ? (kBlock / 64) * 64 * NB : (kBlock / 64) * STAGE_LANES * PITCH;
+    __shared__ __attribute__((aligned(16))) float s_stage[STAGE_FLOATS];
     const uint32_t lane = threadIdx.x & 63u;
-    float *stage = s_stage + (threadIdx.x >> 6) * (STAGE_LANES * PITCH);   // this wave's slots
+    float *stage = s_stage + (threadIdx.x >> 6) * (STAGE_FLOATS / (kBlock / 64));   // this wave's slots
     // The scalar-per-cell contributions -- the density gradient (one per segment: every cell a ray crosses has one,
     // empty cells included) and the three point-gradient components (one triple per lit segment, for the cell before) --
     // are first summed per cell in block-level write-back caches: four direct-mapped tables (density, x, y, z) of
@@ -1736,6 +1749,12 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
     TrailWalker<DEG, HALF, QUANT> W;
     W.init(p);
     const float (&sh)[NB] = W.sh;
+    if constexpr (FROM_BASIS) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) stage[lane * NB + b] = sh[b];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     StepGrad G;
     clear_step(G);
@@ -1760,7 +1779,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                 absorb_stage<4, 1>(lane, G.cur, dact, dv);
                 absorb_stage<8, 1>(lane, G.cur, dact, dv);
                 if (dact && dv[0] != 0.0f)
-                    table_add<DROWS>(s_tab[0], G.cur, dv[0], p.attr_grad + (A - 1), (size_t)A);
+                    table_add<DROWS>(s_tab[0], G.cur, dv[0], p.attr_grad + (A - 1), (size_t)p.attr_pitch);
             }
             // point gradient of the previous cell
             if (ballot(G.has && G.pg_on) != 0ull) {
@@ -1781,7 +1800,29 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
 #endif
             // colour rows: stage lane-major, emit column-major (two rows per pass, a lane per column)
             const bool lit = G.has && G.row;
-            if (ballot(lit) != 0ull) {
+            if constexpr (FROM_BASIS) {
+                unsigned long long todo = ballot(lit);
+                const uint32_t bcol = lane / 3u, ccol = lane - 3u * bcol;   // column `lane` = basis bcol, channel ccol
+                while (todo != 0ull) {
+                    const int src = __builtin_ctzll(todo);
+                    const uint32_t cell = readlane(G.cur, src);
+#if RF_MERGE_ROWS
+                    unsigned long long group = ballot(lit && G.cur == cell);   // every lane of the wave in this cell
+#else
+                    unsigned long long group = 1ull << src;
+#endif
+                    todo &= ~group;
+                    float v = 0.0f;
+                    while (group != 0ull) {
+                        const int m = __builtin_ctzll(group);
+                        group &= group - 1ull;
+                        const float gr = readlane_f(G.dLr, m), gg = readlane_f(G.dLg, m), gb = readlane_f(G.dLb, m);
+                        const float gc = ccol == 0u ? gr : (ccol == 1u ? gg : gb);
+                        if (lane < (uint32_t)NC) v += stage[(uint32_t)m * NB + bcol] * gc;
+                    }
+                    if (lane < (uint32_t)NC && v != 0.0f) grad_add(p.attr_grad + (size_t)cell * p.attr_pitch + lane, v);
+                }
+            } else if (ballot(lit) != 0ull) {
 #pragma unroll
                 for (int half = 0; half < 64 / STAGE_LANES; ++half) {
                     const bool mine = lit && (STAGE_LANES == 64 || (int)(lane / (uint32_t)STAGE_LANES) == half);
@@ -1804,37 +1845,66 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    // Lanes of the wave (of this staged half) whose rows go to the SAME cell leave as one row: the emitting
+                    // lanes sum the group's staged rows column by column (the same LDS reads as emitting them one by one)
+                    // and issue one atomic per column.  What the memory side counts is (instruction, 64-byte line) pairs
+                    // -- 21 G/s chip-wide, scripts/probe/global_atomics.hip -- and a batch whose every segment is lit
+                    // (real training: the scene's softplus never returns exactly 0) is bound by exactly that.
                     if constexpr (NC > 32) {
                         // a row wider than a half-wave goes out as ONE instruction, a lane per column: split at column
                         // 32 the line that holds the boundary was requested twice (5 requests per 192-byte row, 4 now)
                         while (todo != 0ull) {
                             const uint32_t src = (uint32_t)__builtin_ctzll(todo);
-                            todo &= todo - 1ull;
                             const uint32_t cell = readlane(G.cur, (int)src);
-                            const uint32_t slot = src & (uint32_t)(STAGE_LANES - 1);
+#if RF_MERGE_ROWS
+                            unsigned long long group = ballot(mine && G.cur == cell);
+#else
+                            unsigned long long group = 1ull << src;
+#endif
+                            todo &= ~group;
                             if (lane < (uint32_t)NC) {
-                                const float v = stage[slot * PITCH + lane];
-                                if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * A + lane, v);
+                                float v = 0.0f;
+                                while (group != 0ull) {
+                                    const uint32_t m = (uint32_t)__builtin_ctzll(group);
+                                    group &= group - 1ull;
+                                    v += stage[(m & (uint32_t)(STAGE_LANES - 1)) * PITCH + lane];
+                                }
+                                if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * p.attr_pitch + lane, v);
                             }
                         }
                     } else {
                         const uint32_t col0 = lane & 31u;
                         while (todo != 0ull) {
                             const uint32_t b0 = (uint32_t)__builtin_ctzll(todo);
-                            todo &= todo - 1ull;
-                            uint32_t b1 = 64u;
+                            const uint32_t cell0 = readlane(G.cur, (int)b0);
+#if RF_MERGE_ROWS
+                            const unsigned long long g0 = ballot(mine && G.cur == cell0);
+#else
+                            const unsigned long long g0 = 1ull << b0;
+#endif
+                            todo &= ~g0;
+                            unsigned long long g1 = 0ull;
+                            uint32_t cell1 = 0u;
                             if (todo != 0ull) {
-                                b1 = (uint32_t)__builtin_ctzll(todo);
-                                todo &= todo - 1ull;
+                                const uint32_t b1 = (uint32_t)__builtin_ctzll(todo);
+                                cell1 = readlane(G.cur, (int)b1);
+#if RF_MERGE_ROWS
+                                g1 = ballot(mine && G.cur == cell1);
+#else
+                                g1 = 1ull << b1;
+#endif
+                                todo &= ~g1;
                             }
-                            const uint32_t src = lane < 32u ? b0 : b1;       // the lane whose row this half-wave emits
-                            const uint32_t cell = __shfl(G.cur, (int)(src & 63u), 64);
-                            if (src < 64u) {
-                                const uint32_t slot = src & (uint32_t)(STAGE_LANES - 1);
-                                if (col0 < (uint32_t)NC) {
-                                    const float v = stage[slot * PITCH + col0];
-                                    if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * A + col0, v);
+                            unsigned long long group = lane < 32u ? g0 : g1;   // the group this half-wave emits
+                            const uint32_t cell = lane < 32u ? cell0 : cell1;
+                            if (col0 < (uint32_t)NC) {
+                                float v = 0.0f;
+                                while (group != 0ull) {
+                                    const uint32_t m = (uint32_t)__builtin_ctzll(group);
+                                    group &= group - 1ull;
+                                    v += stage[(m & (uint32_t)(STAGE_LANES - 1)) * PITCH + col0];
                                 }
+                                if (v != 0.0f) grad_add(p.attr_grad + (size_t)cell * p.attr_pitch + col0, v);
                             }
                         }
                     }
@@ -1871,7 +1941,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
         const float v = __builtin_bit_cast(float, (uint32_t)ent);
         if (key == kNone || v == 0.0f) continue;
         const uint32_t t = e / (uint32_t)DROWS;
-        if (t == 0u) grad_add(p.attr_grad + (size_t)key * A + (A - 1), v);
+        if (t == 0u) grad_add(p.attr_grad + (size_t)key * p.attr_pitch + (A - 1), v);
         else grad_add(p.points_grad + 3 * (size_t)key + (t - 1u), v);
     }
 }
@@ -2472,6 +2542,9 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     p.point_error = static_cast<float *>(point_error);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
     p.strict = opts->forward_mode == 3u ? 1u : 0u;
+    p.attr_pitch = opts->attr_grad_pitch ? opts->attr_grad_pitch : attribute_dim(sh_degree);
+    if (p.attr_pitch < attribute_dim(sh_degree))
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: attr_grad_pitch smaller than the attribute dimension");
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: trail_slots smaller than rf_trail_slots()");

@@ -255,6 +255,43 @@ __global__ __launch_bounds__(256) void cast_accumulator_kernel(const float *__re
 
 using namespace rf;
 
+// ------------------------------------------------------------------------------------------
+// radfoam.BatchFetcher on the device (src/utils/batch_fetcher.cpp:60-77).  The reference gathers rows of a HOST array on
+// a worker thread and uploads them, four batches ahead; with 288 GB of HBM the whole training set (rays, colours, alphas
+// of every view: a few GB) lives on the device and a batch is one gather kernel: thread per 4-byte word of the batch,
+// row j of batch b taken from  randint(make_rng(b * batch_size + j), 0, n)  (random.h:13-57, restated below: the
+// hash-prospector mixer, then x / (0xffffffff / n) clamped to n - 1) or from (b * batch_size + j) % n without shuffling
+// -- the same index sequence, so fetchers over rays / colours / alphas stay aligned as the reference's do.
+__device__ __forceinline__ uint32_t rng_mix(uint32_t x) {
+    x ^= x >> 17;
+    x *= 0xED5AD4BBu;
+    x ^= x >> 11;
+    x *= 0xAC4C1B51u;
+    x ^= x >> 15;
+    x *= 0x31848BABu;
+    x ^= x >> 14;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void fetch_batch_kernel(const uint32_t *__restrict__ data, uint64_t num_elements,
+                                                          uint32_t words_per_row, uint64_t first, uint32_t batch_size,
+                                                          int shuffle, uint32_t *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= (uint64_t)batch_size * words_per_row) return;
+    const uint32_t j = (uint32_t)(t / words_per_row), w = (uint32_t)(t - (uint64_t)j * words_per_row);
+    const uint64_t seq = first + j;                                  // batch_idx * batch_size + j
+    uint64_t row;
+    if (shuffle) {
+        const uint32_t n = (uint32_t)num_elements;
+        uint32_t x = rng_mix((uint32_t)seq ^ 0x2815DB5Bu) / (0xFFFFFFFFu / n);
+        row = x < n - 1u ? x : n - 1u;
+    } else {
+        row = seq % num_elements;
+    }
+    out[t] = data[row * words_per_row + w];
+}
+
+
 extern "C" {
 
 int rf_pack_attributes(int sh_degree, int attr_type, uint32_t num_points, const float *att_dc,
@@ -343,6 +380,25 @@ int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_
                        static_cast<hipStream_t>(stream), points, point_adjacency, point_adjacency_offsets,
                        num_points, indices, cell_radius);
     return check_launch("rf_farthest_neighbor");
+}
+
+
+int rf_fetch_batch(const void *data, uint64_t num_elements, uint32_t stride_bytes, uint32_t batch_index,
+                   uint32_t batch_size, int shuffle, void *out, void *stream) {
+    g_err[0] = 0;
+    if (batch_size == 0) return RF_OK;
+    if (!data || !out) return fail(RF_ERR_INVALID_ARGUMENT, "rf_fetch_batch: null pointer");
+    if (num_elements == 0 || num_elements > 0xFFFFFFFFull)
+        return fail(RF_ERR_INVALID_ARGUMENT, num_elements ? "Too many elements" : "rf_fetch_batch: no elements");
+    if (stride_bytes == 0 || (stride_bytes & 3u))
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_fetch_batch: stride must be a positive multiple of 4 bytes");
+    const uint32_t words = stride_bytes / 4u;
+    const uint64_t total = (uint64_t)batch_size * words;
+    if (total > 0xFFFFFFFFull * 256ull) return fail(RF_ERR_INVALID_ARGUMENT, "rf_fetch_batch: batch too large");
+    hipLaunchKernelGGL(fetch_batch_kernel, dim3((unsigned)((total + 255u) / 256u)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint32_t *>(data), num_elements, words,
+                       (uint64_t)batch_index * (uint64_t)batch_size, batch_size, shuffle, static_cast<uint32_t *>(out));
+    return check_launch("rf_fetch_batch");
 }
 
 

@@ -105,8 +105,8 @@ def all_reduce_gradients(backward_result: dict, group=None, async_op: bool = Fal
     handles = []
     flat = backward_result.get("flat_grad")
     attr = backward_result["attr_grad"]
-    if flat is not None and attr.dtype == flat.dtype and attr.data_ptr() == flat.data_ptr() + \
-            backward_result["points_grad"].numel() * flat.element_size():
+    if flat is not None and attr.dtype == flat.dtype and \
+            attr.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr():     # attr_grad is a view of flat
         handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
     else:
         handles.append(dist.all_reduce(backward_result["points_grad"], op=dist.ReduceOp.SUM, group=group,
@@ -295,6 +295,9 @@ class ShardedTracer:
         self.group = group
         self.bounds = None
         self.sparse = SparseGradExchange(group) if exchange == "sparse" else None
+        if self.sparse is not None and hasattr(pipeline, "gradient_row_pitch"):
+            # rf_compact_grad_rows / rf_scatter_grad_rows read and write the reference's dense [N][A] rows
+            pipeline.gradient_row_pitch = "dense"
 
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1

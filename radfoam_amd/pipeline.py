@@ -218,6 +218,10 @@ class Pipeline:
         #: (tracing_utils.cuh:43-67) in trace_forward, trace_backward and trace_benchmark: the reference's tie-breaking
         #: where two exits agree to an ulp, at the price of a divide per face (``strict_reference_scan`` sets it)
         self.forward_mode = 0
+        #: layout of the attr_grad accumulator: "auto" = rows on 64-byte lines at a pitch of 16 / 32 / 64 floats (fewer
+        #: atomic line requests per gradient row; trace_backward then returns attr_grad as a [N, A] view of the padded
+        #: rows), "dense" = the reference's contiguous [N, A] (radfoam_amd.dist's sparse exchange needs it), or an int
+        self.gradient_row_pitch = "auto"
         #: experiment builds only (scripts/): int64 device tensor handed to rf_trace_backward as rf_launch_opts.stats
         self.experiment_stats = None
         #: image-shaped batches: the order in which the blocks of a launch take the 16x16 tiles (rf_launch_opts.tile_order),
@@ -293,6 +297,18 @@ class Pipeline:
     @strict_reference_scan.setter
     def strict_reference_scan(self, on):
         self.forward_mode = 3 if on else 0
+
+    def _gradient_pitch(self) -> int:
+        """Floats between two rows of the attr_grad accumulator (rf_launch_opts.attr_grad_pitch)."""
+        a = self._attr_dim
+        if self.gradient_row_pitch == "dense":
+            return a
+        if self.gradient_row_pitch == "auto":
+            return {4: 4, 13: 16, 28: 32, 49: 64}[a]
+        pitch = int(self.gradient_row_pitch)
+        if pitch < a:
+            raise RuntimeError("gradient_row_pitch must be at least the attribute dimension")
+        return pitch
 
     def invalidate(self):
         """Forget the cached packed foam, hop trail and ray order of this Pipeline (and free the trail).
@@ -786,11 +802,16 @@ class Pipeline:
         settings = self._settings(weight_threshold, max_intersections)
 
         # one flat fp32 buffer [points_grad | attr_grad] so a data-parallel caller can all-reduce
-        # both with a single collective (radfoam_amd/dist.py)
+        # both with a single collective (radfoam_amd/dist.py).  The attr_grad rows sit on 64-byte lines at a pitch of
+        # 16 / 32 / 64 floats (gradient_row_pitch "auto"): a row leaves the kernels as one atomic instruction and the
+        # memory side works per (instruction, line) -- see rf_launch_opts.attr_grad_pitch; the returned attr_grad is then a
+        # [N, A] VIEW of [N, pitch] rows (same values; .contiguous() gives the reference's dense layout).
         a = self._attr_dim
-        flat = torch.zeros(num_points * (3 + a), dtype=torch.float32, device=dev)
+        pitch = self._gradient_pitch()
+        head = (num_points * 3 + 15) // 16 * 16 if pitch != a else num_points * 3
+        flat = torch.zeros(head + num_points * pitch, dtype=torch.float32, device=dev)
         points_grad = flat[: num_points * 3].view(num_points, 3)
-        attr_grad = flat[num_points * 3:].view(num_points, a)
+        attr_grad = flat[head:].view(num_points, pitch)[:, :a]
         ray_grad = torch.zeros_like(rays_c)
 
         out = {
@@ -820,6 +841,7 @@ class Pipeline:
             opts.trail_slots = tr["slots"]
         if self.experiment_stats is not None:
             opts.stats = self.experiment_stats.data_ptr()
+        opts.attr_grad_pitch = pitch
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_backward(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),

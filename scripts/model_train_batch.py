@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--sh", type=int, default=3)
     ap.add_argument("--cap", type=int, default=384)
     ap.add_argument("--image", action="store_true", help="a 1080p frame in 16x16 tiles instead (the dense reference point)")
+    ap.add_argument("--all-lit", action="store_true",
+                    help="row combining with every segment lit (real training: softplus never returns exactly 0)")
     args = ap.parse_args()
     fm = foam.make_synthetic_foam(args.points, args.sh, args.seed, cache_dir=foam.default_cache_dir())
     if args.image:
@@ -260,7 +262,7 @@ def main():
     result["density_gradient_combining"] = wb
     print("density gradient combining", json.dumps(wb))
     rc = collections.Counter()
-    lit_mask = np.concatenate([dens > 1e-6, [False]])   # index N (none) never lit
+    lit_mask = np.concatenate([(dens > 1e-6) | args.all_lit, [False]])   # index N (none) never lit
     safe = np.where(cells == O.NONE, args.points, cells).astype(np.int64)
     for b in range(pick.size):
         sl = slice(b * 256, (b + 1) * 256)

@@ -45,7 +45,8 @@ def test_struct_layouts_match_header():
     assert _lib.LaunchOpts.trail.offset == 40 and _lib.LaunchOpts.trail_cap.offset == 56
     assert _lib.LaunchOpts.ray_order.offset == 64 and _lib.LaunchOpts.visit_marks.offset == 72
     assert _lib.LaunchOpts.forward_mode.offset == 80 and _lib.LaunchOpts.tile_order.offset == 88
-    assert _lib.LaunchOpts.tile_cost.offset == 96 and ctypes.sizeof(_lib.LaunchOpts) == 104
+    assert _lib.LaunchOpts.tile_cost.offset == 96 and _lib.LaunchOpts.attr_grad_pitch.offset == 104
+    assert ctypes.sizeof(_lib.LaunchOpts) == 112
 
 
 def test_host_only_entry_points():

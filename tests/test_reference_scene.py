@@ -285,3 +285,46 @@ def test_no_grad_renders_of_the_reference_scene_record_no_trail(ref_model):
     assert model.pipeline._trail is None
     model(rays)
     assert model.pipeline._trail is not None
+
+
+def _loop_case(device, points, sh, **kw):
+    """examples/train_loop.py (what `bench.py --workload train-loop` runs) on a small foam."""
+    from examples import train_loop
+    from radfoam_amd import foam
+    fm = foam.make_synthetic_foam(points, sh, 13)
+    env = {"torch": torch, "dev": torch.device(device)}
+    its, detail = train_loop.run(None, env, fm, sh_degree=sh, **kw)
+    per = detail["ms_per_iteration"]
+    assert its > 0 and detail["iterations"] == kw["iterations"]
+    assert per["tracer_forward"] > 0 and per["tracer_backward"] > 0 and per["optimizer_step"] > 0
+    assert detail["calls_by_section"]["tracer_forward"] == kw["iterations"]          # densification booked apart
+    assert detail["calls_by_section"]["tracer_backward"] == kw["iterations"]
+    # train.py:243-248: rebuilds after iterations 0, 3, 8, 15, ... (period 1, +2 per rebuild)
+    want = sum(1 for k in range(1, 100) if k * k <= kw["iterations"])
+    assert detail["rebuilds"]["incremental"] >= want
+    assert all(np.isfinite(l) for _, l in detail["loss_trace"])
+    return detail
+
+
+def test_train_loop_script_dry_run_on_the_cpu_shims(ref_model, monkeypatch):
+    """CPU: the loop's own logic (fetchers, quantiles, losses, rebuild schedule, section bookkeeping) with the tracer
+    replaced by the oracle behind the Pipeline interface; no densification (collect_error_map needs .cuda())."""
+    import radfoam
+    monkeypatch.setattr(radfoam, "create_pipeline", lambda d, dt="float32": _OraclePipeline(d, dt))
+    d = _loop_case("cpu", 1500, 1, iterations=5, rays_per_batch=1500, cameras=2, width=48, height=32,
+                   densify_at=10 ** 9)
+    assert d["densification"] is None and d["rebuilds"]["full"] == 0
+
+
+@pytest.mark.gpu
+def test_train_loop_smoke_on_the_gpu(ref_model):
+    """-m gpu smoke of `bench.py --workload train-loop`: the reference's RadFoamScene through 24
+    iterations of the loop with the rebuild schedule and one densification, HIP tracer + GPU triangulation + the
+    device-resident BatchFetcher."""
+    d = _loop_case("cuda", 20_000, 3, iterations=24, rays_per_batch=30_000, cameras=3, width=160, height=120,
+                   densify_at=12)
+    dens = d["densification"]
+    # prune_and_densify adds 15 % and prunes what contributes nothing (the synthetic foam's empty shell): the count changes
+    assert dens is not None and dens["points_after"] != dens["points_before"] and d["rebuilds"]["full"] == 1
+    assert 32 < dens["points_after"] <= int(1.15 * dens["points_before"]) + 1
+    assert d["calls_by_section"]["densification:tracer_forward"] == 3                 # one per training view

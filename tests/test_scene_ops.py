@@ -262,3 +262,40 @@ def test_triangulation_on_gpu_builds_the_same_csr():
     assert gpu.point_adjacency().is_cuda
     np.testing.assert_array_equal(gpu.point_adjacency().cpu().numpy(), cpu.point_adjacency().numpy())
     np.testing.assert_array_equal(gpu.point_adjacency_offsets().cpu().numpy(), cpu.point_adjacency_offsets().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shuffle", [True, False])
+def test_batch_fetcher_on_the_device_follows_the_references_index_sequence(shuffle):
+    """radfoam.BatchFetcher with a GPU present keeps the array in HBM and gathers a batch with one kernel
+    (rf_fetch_batch); the rows it returns are those of the reference's index sequence (batch_fetcher.cpp:60-70,
+    random.h:13-57 -- restated in numpy by the shim's own CPU path), for rays (24-byte rows), colours (12) and alphas
+    (4) alike, so that the three fetchers of train.py stay aligned; the batch counter carries over the wrap of
+    b * batch_size + j."""
+    import radfoam
+    from radfoam_amd import shims
+
+    rng = np.random.default_rng(5)
+    n, bs = 100_003, 4096
+    for width in (6, 3, 1):
+        data = torch.from_numpy(rng.normal(size=(n, width)).astype(np.float32))
+        f = radfoam.BatchFetcher(data, bs, shuffle)
+        assert f._native and f.data.is_cuda
+        ref = shims.BatchFetcher.__new__(shims.BatchFetcher)      # the numpy index path of the same class
+        ref.data, ref.batch_size, ref.shuffle, ref.batch_idx = data, bs, shuffle, 0
+        for b in range(3):
+            want = data[torch.from_numpy(ref._indices())]
+            ref.batch_idx += 1
+            got = f.next()
+            assert got.shape == (bs, width) and got.is_cuda
+            assert torch.equal(got.cpu(), want), (width, b)
+    # an image-shaped array with batch_size 1, as collect_error_map / test_render use it (scene.py:505-512)
+    imgs = torch.from_numpy(rng.normal(size=(5, 8, 12, 6)).astype(np.float32))
+    f = radfoam.BatchFetcher(imgs, 1, False)
+    for b in range(7):
+        assert torch.equal(f.next().cpu(), imgs[b % 5][None])
+    # far into a run: batch index times batch size beyond 2^32
+    f = radfoam.BatchFetcher(data, bs, shuffle)
+    ref.data, ref.batch_idx = data, (1 << 32) // bs + 7
+    f.batch_idx = ref.batch_idx
+    assert torch.equal(f.next().cpu(), data[torch.from_numpy(ref._indices())])
