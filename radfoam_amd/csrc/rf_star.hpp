@@ -642,76 +642,43 @@ RF_STAR_FN float box_dist2(const float *nd, float x, float y, float z) {
     return dx * dx + dy * dy + dz * dz;
 }
 
-// The point in strict conflict with triangle t that is closest to p_i, or kInfinity if there is none: depth-first
-// through the implicit tree, nearer child first, boxes pruned against the triangle's ball (half-space) and against
-// the best candidate so far.  `visited` counts tree nodes (instrumentation).
+// The region a query asks about (triangle t of the star of p_i), in the form the tree walk tests boxes and points with.
+struct Region {
+    float px, py, pz;      // p_i
+    float nx, ny, nz;      // centre of the ball relative to p_i / outward normal of a ghost's plane
+    float cx, cy, cz;      // centre of the ball, absolute
+    float r2, rp2;         // squared radius as cached in the triangle / padded for the roundings of centre and box distance
+    uint32_t g0, g1, g2;   // the triangle's own vertices
+    uint8_t f;
+    bool ghost, ball;
+};
+
+// Depth-first walk of the subtree rooted at node k0 of level d0 and then, one after the other, of the sibling subtrees
+// of p_i's ancestors at the levels whose bits are set in `reach` (deepest first); nearer child first, boxes pruned
+// against the region and against the best candidate so far; keeps the conflicting point closest to p_i in (best,
+// best_id, out_q).  Returns false when the query's budget of tree nodes ran out (see HullSet).
 template <typename S>
-RF_STAR_FN uint32_t star_search(S &s, const Tree &tr, const float *pts, int t, const HullSet &hull,
-                                float *out_q, uint32_t &visited) {
-    const uint8_t f = s.t[t].f;
-    const bool ghost = (f & kGhost) != 0;
-    const bool ball = !ghost && s.t[t].sr < 3.0e38f;
-    const float px = s.p[0], py = s.p[1], pz = s.p[2];
-    const uint32_t g0 = s.v[s.t[t].a].g, g1 = s.v[s.t[t].b].g, g2 = s.v[s.t[t].c].g;
-    if (ghost && hull.ids) {
-        // second pass: whatever lies beyond a plane, a vertex of the convex hull lies beyond it too, and the hull's
-        // vertices are among the few points whose first-pass star kept a ghost
-        float best = 3.4e38f;
-        uint32_t best_id = kInfinity;
-        for (uint32_t h = 0; h < hull.count; ++h) {
-            const uint32_t k = hull.ids[h];
-            if (k == s.self || k == g0 || k == g1 || k == g2) continue;
-            const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
-            const float dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 == 0.0f && q[0] == px && q[1] == py && q[2] == pz) s.status = kDuplicate;
-            if (!(d2 < best) || !conflict(s, t, q)) continue;
-            best = d2;
-            best_id = k;
-            out_q[0] = q[0];
-            out_q[1] = q[1];
-            out_q[2] = q[2];
-        }
-        visited += hull.count;
-        return best_id;
-    }
-    const uint32_t budget = hull.budget;
-    uint32_t spent = 0;
-    const float nx = s.t[t].sx, ny = s.t[t].sy, nz = s.t[t].sz;
-    // ball in absolute coordinates, radius padded for the roundings of centre and box distance
-    const float cx = px + nx, cy = py + ny, cz = pz + nz;
-    float rp2 = 3.4e38f;
-    const float s_r2 = s.t[t].sr;
-    if (ball) {
-        const float r = sqrtf(s_r2);
-        const float pad = 4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + fabsf(nx) + fabsf(ny) + fabsf(nz) + r);
-        const float rp = (r + pad) * 1.000002f;
-        rp2 = rp * rp;
-    }
+RF_STAR_FN bool search_subtree(S &s, const Tree &tr, const float *pts, int t, const Region &R, uint32_t d0, uint32_t k0,
+                               uint32_t reach, float &best, uint32_t &best_id, float *out_q, uint32_t &visited,
+                               uint32_t &spent, uint32_t budget) {
     const uint32_t leaf_depth = tr.depth - kLeafBits;
-    float best = 3.4e38f;
-    uint32_t best_id = kInfinity;
-    uint32_t depth = 0, vidx = 0, flip = 0;
+    uint32_t ld = 0, vidx = 0, flip = 0;   // coordinates inside the subtree: level and position below (d0, k0)
     for (;;) {
-        const uint32_t idx = vidx ^ flip;
+        const uint32_t depth = d0 + ld;
+        const uint32_t idx = (k0 << ld) | (vidx ^ flip);
         const uint32_t first = idx << (tr.depth - depth);
         bool descend = false;
         if (first < tr.n) {
             const float *nd = tree_node(tr, depth, idx);
             ++visited;
-            if (++spent > budget) {
-                // out of budget (see HullSet): any conflicting point found so far will do; with none, the star
-                // waits for the second pass
-                if (best_id == kInfinity) s.status = kPending;
-                return best_id;
-            }
-            bool ok = box_dist2(nd, px, py, pz) < best;
-            if (ok && ball) ok = box_dist2(nd, cx, cy, cz) <= rp2;
-            if (ok && ghost && !(f & kSlow)) {
+            if (++spent > budget) return false;
+            bool ok = box_dist2(nd, R.px, R.py, R.pz) < best;
+            if (ok && R.ball) ok = box_dist2(nd, R.cx, R.cy, R.cz) <= R.rp2;
+            if (ok && R.ghost && !(R.f & kSlow)) {
                 // largest value of n . (x - p) over the box
-                const float ax = nx > 0 ? nd[3] - px : nd[0] - px, ay = ny > 0 ? nd[4] - py : nd[1] - py;
-                const float az = nz > 0 ? nd[5] - pz : nd[2] - pz;
-                const float tx = nx * ax, ty = ny * ay, tz = nz * az;
+                const float ax = R.nx > 0 ? nd[3] - R.px : nd[0] - R.px, ay = R.ny > 0 ? nd[4] - R.py : nd[1] - R.py;
+                const float az = R.nz > 0 ? nd[5] - R.pz : nd[2] - R.pz;
+                const float tx = R.nx * ax, ty = R.ny * ay, tz = R.nz * az;
                 ok = tx + ty + tz > -4e-6f * (fabsf(tx) + fabsf(ty) + fabsf(tz));
             }
             if (ok) {
@@ -720,18 +687,18 @@ RF_STAR_FN uint32_t star_search(S &s, const Tree &tr, const float *pts, int t, c
                 } else {
                     const uint32_t end = first + (1u << kLeafBits) < tr.n ? first + (1u << kLeafBits) : tr.n;
                     for (uint32_t k = first; k < end; ++k) {
-                        if (k == s.self || k == g0 || k == g1 || k == g2) continue;
+                        if (k == s.self || k == R.g0 || k == R.g1 || k == R.g2) continue;
                         const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
-                        const float dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
+                        const float dx = q[0] - R.px, dy = q[1] - R.py, dz = q[2] - R.pz;
                         const float d2 = dx * dx + dy * dy + dz * dz;
-                        if (d2 == 0.0f && q[0] == px && q[1] == py && q[2] == pz) s.status = kDuplicate;
+                        if (d2 == 0.0f && q[0] == R.px && q[1] == R.py && q[2] == R.pz) s.status = kDuplicate;
                         if (!(d2 < best)) continue;
                         // the float filter of conflict(), from the copy of the sphere this walk holds in registers
                         // (the star lives in scratch: every lane asks about another triangle here, and a scattered
                         // scratch read costs a cache line per dword)
-                        if (ball && !(f & kSlow)) {
-                            const float ex = dx - nx, ey = dy - ny, ez = dz - nz;
-                            const float e2 = ex * ex + ey * ey + ez * ez, r2 = s_r2;
+                        if (R.ball && !(R.f & kSlow)) {
+                            const float ex = dx - R.nx, ey = dy - R.ny, ez = dz - R.nz;
+                            const float e2 = ex * ex + ey * ey + ez * ez, r2 = R.r2;
                             if (e2 > r2 + 4e-6f * (e2 + r2) + 1e-37f) continue;
                             if (!(e2 < r2 - (4e-6f * (e2 + r2) + 1e-37f)) && !conflict(s, t, q)) continue;
                         } else if (!conflict(s, t, q)) {
@@ -750,21 +717,125 @@ RF_STAR_FN uint32_t star_search(S &s, const Tree &tr, const float *pts, int t, c
             // the children of a level-d node are separated along axis d % 3 (kd-order): nearer one first
             const uint32_t dim = depth % 3;
             const float *left = tree_node(tr, depth + 1, 2 * idx);
-            const float pd = dim == 0 ? px : (dim == 1 ? py : pz);
+            const float pd = dim == 0 ? R.px : (dim == 1 ? R.py : R.pz);
             const uint32_t right_first = pd > left[3 + dim] ? 1u : 0u;
-            ++depth;
+            ++ld;
             vidx <<= 1;
             flip = (flip << 1) | right_first;
             continue;
         }
         ++vidx;
         uint32_t up = (uint32_t)__builtin_ctz(vidx);
-        up = up < depth ? up : depth;
-        depth -= up;
+        up = up < ld ? up : ld;
+        ld -= up;
         vidx >>= up;
         flip >>= up;
-        if (depth == 0) break;
+        if (ld == 0) {
+            // this subtree is done: on to the next one the caller listed -- the sibling of the ancestor of p_i at the
+            // deepest level whose bit is set in `reach` -- in the SAME loop: one trip is one node for every lane of a
+            // wave, whichever subtree each of them is in (a loop per subtree made the lanes wait for each other at
+            // every level: 2M points from scratch 502 ms against 355)
+            if (reach == 0u) break;
+            d0 = 31u - (uint32_t)__builtin_clz(reach);
+            reach &= ~(1u << d0);
+            k0 = (s.self >> (tr.depth - d0)) ^ 1u;
+            vidx = flip = 0;
+        }
     }
+    return true;
+}
+
+// The point in strict conflict with triangle t that is closest to p_i, or kInfinity if there is none.  `visited`
+// counts tree nodes (instrumentation).
+//
+// A finite ball passes through p_i, so what it can hold sits near p_i's own leaf of the tree: the walk goes BOTTOM-UP
+// (RF_STAR_BOTTOM_UP, default) -- p_i's bucket first, then the sibling subtree of every ancestor of that bucket, from
+// the leaves to the root.  Every point of the cloud lies in exactly one of these subtrees, so nothing is missed whatever
+// the boxes look like (an incremental rebuild walks the boxes of points that moved after they were sorted: siblings may
+// overlap then, which this does not care about).  Against the root-first walk it visits one box per level instead of
+// two -- the ancestors themselves are never tested -- and, what matters more for a kernel that waits on dependent loads
+// (waves parked 79 % of their cycles), the siblings' addresses follow from the lane's own index: the
+// first phase tests all of them against the ball with independent loads and leaves a bit per level, the second walks
+// into the few that the ball reaches.  Half-spaces (ghosts) and the balls of flat tetrahedra, which no box bounds,
+// still start at the root.
+#ifndef RF_STAR_BOTTOM_UP
+#define RF_STAR_BOTTOM_UP 1
+#endif
+template <typename S>
+RF_STAR_FN uint32_t star_search(S &s, const Tree &tr, const float *pts, int t, const HullSet &hull,
+                                float *out_q, uint32_t &visited) {
+    Region R;
+    R.f = s.t[t].f;
+    R.ghost = (R.f & kGhost) != 0;
+    R.ball = !R.ghost && s.t[t].sr < 3.0e38f;
+    R.px = s.p[0];
+    R.py = s.p[1];
+    R.pz = s.p[2];
+    R.g0 = s.v[s.t[t].a].g;
+    R.g1 = s.v[s.t[t].b].g;
+    R.g2 = s.v[s.t[t].c].g;
+    if (R.ghost && hull.ids) {
+        // second pass: whatever lies beyond a plane, a vertex of the convex hull lies beyond it too, and the hull's
+        // vertices are among the few points whose first-pass star kept a ghost
+        float best = 3.4e38f;
+        uint32_t best_id = kInfinity;
+        for (uint32_t h = 0; h < hull.count; ++h) {
+            const uint32_t k = hull.ids[h];
+            if (k == s.self || k == R.g0 || k == R.g1 || k == R.g2) continue;
+            const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
+            const float dx = q[0] - R.px, dy = q[1] - R.py, dz = q[2] - R.pz;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 == 0.0f && q[0] == R.px && q[1] == R.py && q[2] == R.pz) s.status = kDuplicate;
+            if (!(d2 < best) || !conflict(s, t, q)) continue;
+            best = d2;
+            best_id = k;
+            out_q[0] = q[0];
+            out_q[1] = q[1];
+            out_q[2] = q[2];
+        }
+        visited += hull.count;
+        return best_id;
+    }
+    const uint32_t budget = hull.budget;
+    uint32_t spent = 0;
+    R.nx = s.t[t].sx;
+    R.ny = s.t[t].sy;
+    R.nz = s.t[t].sz;
+    // ball in absolute coordinates, radius padded for the roundings of centre and box distance
+    R.cx = R.px + R.nx;
+    R.cy = R.py + R.ny;
+    R.cz = R.pz + R.nz;
+    R.rp2 = 3.4e38f;
+    R.r2 = s.t[t].sr;
+    if (R.ball) {
+        const float r = sqrtf(R.r2);
+        const float pad = 4e-7f * (fabsf(R.px) + fabsf(R.py) + fabsf(R.pz) + fabsf(R.nx) + fabsf(R.ny) + fabsf(R.nz) + r);
+        const float rp = (r + pad) * 1.000002f;
+        R.rp2 = rp * rp;
+    }
+    float best = 3.4e38f;
+    uint32_t best_id = kInfinity;
+    bool in_budget = true;
+    const uint32_t leaf_depth = tr.depth - kLeafBits;
+    if (RF_STAR_BOTTOM_UP && R.ball && leaf_depth >= 1u && leaf_depth < 32u) {
+        // phase 1: which ancestors' siblings does the ball reach?  (independent loads: addresses from s.self alone)
+        uint32_t reach = 0;
+        for (uint32_t d = leaf_depth; d >= 1u; --d) {
+            const uint32_t sib = (s.self >> (tr.depth - d)) ^ 1u;
+            if ((sib << (tr.depth - d)) >= tr.n) continue;
+            if (box_dist2(tree_node(tr, d, sib), R.cx, R.cy, R.cz) <= R.rp2) reach |= 1u << d;
+        }
+        visited += leaf_depth;
+        spent += leaf_depth;
+        // phase 2: p_i's own bucket, then the reached siblings from the nearest level up (one loop: see search_subtree)
+        in_budget = search_subtree(s, tr, pts, t, R, leaf_depth, s.self >> kLeafBits, reach, best, best_id, out_q,
+                                   visited, spent, budget);
+    } else {
+        in_budget = search_subtree(s, tr, pts, t, R, 0u, 0u, 0u, best, best_id, out_q, visited, spent, budget);
+    }
+    // out of budget (see HullSet): any conflicting point found so far will do; with none, the star waits for the
+    // second pass
+    if (!in_budget && best_id == kInfinity) s.status = kPending;
     return best_id;
 }
 
