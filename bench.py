@@ -133,6 +133,10 @@ def parse_args(argv=None):
                     help="raise the foam's zero densities to this value (4.5e-6 = activation_scale * softplus(-1, beta=10), "
                          "what the reference's scene gives its empty cells, scene.py:459): every segment is then 'lit' "
                          "(> 1e-6), as in real training, where softplus never returns exactly 0")
+    ap.add_argument("--strict-scan", action="store_true",
+                    help="Pipeline.strict_reference_scan: the reference's per-face quotient scan (tracing_utils.cuh:43-67, "
+                         "rf_launch_opts.forward_mode 3) in forward, backward and render; the CPU baseline then runs the "
+                         "oracle in its 'reference' scan mode, so that the bitwise comparison still holds")
     ap.add_argument("--grad-pitch", default=None, help="Pipeline.gradient_row_pitch: auto (default), dense, or floats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
@@ -446,6 +450,10 @@ def run_workload(args, W, env):
         pipe.record_trail = not W["forward_only"]   # trace_backward is driven by hand on plain tensors
         if args.tile_order is not None:
             pipe.tile_order_mode = None if args.tile_order == "static" else args.tile_order
+        if args.strict_scan:
+            pipe.strict_reference_scan = True
+            W["custom"] = True
+            W["label"] += ", the reference's quotient scan (forward_mode 3)"
         if args.grad_pitch is not None:
             pipe.gradient_row_pitch = args.grad_pitch if args.grad_pitch in ("auto", "dense") else int(args.grad_pitch)
     else:
@@ -720,7 +728,7 @@ def run_workload(args, W, env):
     if on_gpu and not args.no_cpu_baseline and world == 1:
         try:
             if W["kind"] == "render":
-                result["cpu_baseline"] = cpu_baseline_render(W, fm, cam, start_np, render_out)
+                result["cpu_baseline"] = cpu_baseline_render(W, fm, cam, start_np, render_out, args.strict_scan)
             else:
                 result["cpu_baseline"] = cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba,
                                                       (points, attributes, adjacency, offsets), quantiles, depth_grad)
@@ -872,6 +880,8 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
         t2 = time.perf_counter()
         return r.size // 6, t1 - t0, t2 - t1, f, b, (r, s, g, sl, q, dg)
 
+    if args.strict_scan:
+        O.lib().rfo_set_scan_mode(1)      # for the rest of this process: the oracle scans the way the reference writes it
     stride = 24
     n, tf, tb, f, b, smp = run(stride)
     for _ in range(2):   # the pilot is dominated by thread start-up: size the sample in two passes
@@ -931,12 +941,14 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
     return out
 
 
-def cpu_baseline_render(W, fm, cam, start_np, render_out):
+def cpu_baseline_render(W, fm, cam, start_np, render_out, strict_scan=False):
     """The render path's CPU baseline: the oracle's restatement of the benchmark kernel (pipeline.cu:472-544 + cast_ray +
     make_rgba8) on the SAME camera, whole frame, all host cores; its RGBA8 words against the frame the GPU just wrote."""
     from oracle import oracle as O
 
     cores = int(O.lib().rfo_max_threads())
+    if strict_scan:
+        O.lib().rfo_set_scan_mode(1)
     half_attrs = fm["attributes"].astype(np.float16)     # what benchmark.py feeds the fp16 pipeline (benchmark.py:36)
     diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"])
     start = np.uint32(np.asarray(start_np).reshape(-1)[0])

@@ -1317,6 +1317,11 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 //     with one coalesced row of global atomics each, skipping zeros; rows still in use stay.
 //     A lane whose key finds no free row adds straight to global memory instead (must stay rare:
 //     scattered global atomics are the slow path this cache exists to avoid).
+// Measured out in round 4 (profiles/r04/b_image_backward_refcount_cache_ab.log; the code is in commit 29902d7): the same
+// cache WITHOUT block barriers -- a reference count per row, every wave sweeping a rotating quarter of the rows every
+// four of its own steps -- runs the benchmark frame's backward in 4.18 ms against 3.75 (config 2: 3.42 against 3.06):
+// two more LDS atomics and a key re-read per lane access cost more than the two barriers per epoch, and the waves of a
+// tile, which share most of their cells, gain nothing from drifting apart.
 
 #ifndef RF_CACHE_PROBES
 #define RF_CACHE_PROBES 8
@@ -1347,9 +1352,6 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
 #endif
 #ifndef RF_DIRECT_WAVES_D3
 #define RF_DIRECT_WAVES_D3 3
-#endif
-#ifndef RF_CACHE_REFCOUNT
-#define RF_CACHE_REFCOUNT 0
 #endif
 #ifndef RF_MERGE_ROWS
 #define RF_MERGE_ROWS 1
@@ -1440,92 +1442,6 @@ __device__ __forceinline__ void cache_flush(double *rows, uint32_t *keys, uint8_
                 }
             }
         }
-    }
-}
-
-// ---- the same cache without block barriers (RF_CACHE_REFCOUNT) ---------------------------------------------------------
-// The epoch protocol above evicts between two block barriers: every four steps the four waves of a tile wait for each
-// other twice (22 % of a step on the benchmark frame, and what a small launch's floor is made of).  Here a row is
-// protected by a reference count instead: a lane that found its row takes a reference, re-reads the key, adds, and drops
-// the reference; a sweep -- each wave, every kEpoch of its own steps, over a quarter of the rows that rotates -- takes a
-// row that was not touched since the last sweep by swapping its key for kEvicting and proceeds only if nobody holds a
-// reference (an adder that arrives later sees the other key and goes elsewhere; one that arrived earlier is seen by its
-// count, and the sweep puts the key back).  No wave ever waits for another one inside the walk.
-constexpr uint32_t kEvicting = 0xFFFFFFFEu;
-
-template <int ROWS>
-__device__ __forceinline__ int cache_acquire(uint32_t *keys, uint32_t *refs, uint32_t key) {
-    const uint32_t h = (((key * 2654435761u) >> 16) * (uint32_t)ROWS) >> 16;
-#pragma unroll
-    for (int probe = 0; probe < kCacheProbes; ++probe) {
-        uint32_t slot = h + (uint32_t)probe;
-        slot = slot >= (uint32_t)ROWS ? slot - (uint32_t)ROWS : slot;
-        const uint32_t old = atomicCAS(&keys[slot], kNone, key);
-        if (old == kNone || old == key) {
-            atomicAdd(&refs[slot], 1u);
-            if (__atomic_load_n(&keys[slot], __ATOMIC_RELAXED) == key) return (int)slot;
-            atomicSub(&refs[slot], 1u);    // a sweep took the row in between: as if it had not been there
-        }
-    }
-    return -1;
-}
-
-// one wave sweeps rows [first, first + count): untouched rows without references go to memory, two per instruction
-template <int NB>
-__device__ __forceinline__ void cache_sweep(double *rows, uint32_t *keys, uint32_t *refs, uint8_t *touch, uint32_t first,
-                                            uint32_t count, bool all, float *attr_grad, float *points_grad,
-                                            uint32_t pitch) {
-    using L = CacheLayout<NB>;
-    constexpr int A = 1 + 3 * NB;
-    const uint32_t lane = threadIdx.x & 63u, col0 = lane & 31u;
-    for (uint32_t base = first; base < first + count; base += 64u) {
-        const uint32_t r = base + lane;
-        uint32_t my_key = kNone;
-        bool evict = false;
-        if (r < first + count) {
-            const uint32_t k = __atomic_load_n(&keys[r], __ATOMIC_RELAXED);
-            if (k != kNone && k != kEvicting) {
-                if (!all && touch[r] != (uint8_t)0) {
-                    touch[r] = (uint8_t)0;
-                } else if (atomicCAS(&keys[r], k, kEvicting) == k) {
-                    if (__atomic_load_n(&refs[r], __ATOMIC_RELAXED) != 0u) {
-                        __atomic_store_n(&keys[r], k, __ATOMIC_RELAXED);    // in use: next time
-                    } else {
-                        evict = true;
-                        my_key = k;
-                    }
-                }
-            }
-        }
-        unsigned long long todo = ballot(evict);
-        while (todo != 0ull) {
-            const uint32_t b0 = (uint32_t)__builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            uint32_t b1 = 64u;
-            if (todo != 0ull) {
-                b1 = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1ull;
-            }
-            const uint32_t mine = lane < 32u ? b0 : b1;
-            const uint32_t key = __shfl(my_key, (int)(mine & 63u), 64);
-            if (mine < 64u) {
-                const uint32_t row = base + mine;
-                for (uint32_t col = col0; col < (uint32_t)L::NCOL; col += 32u) {
-                    double *cell = rows + row * L::STRIDE + col;
-                    const float v = (float)*cell;
-                    if (v != 0.0f) {
-                        *cell = 0.0;
-                        float *dst;
-                        if (col < (uint32_t)L::NCOEF) dst = attr_grad + (size_t)key * pitch + col;
-                        else if (col == (uint32_t)L::COL_DS) dst = attr_grad + (size_t)key * pitch + (A - 1);
-                        else dst = points_grad + 3 * (size_t)key + (col - (uint32_t)L::COL_PG);
-                        grad_add(dst, v);
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (evict) __atomic_store_n(&keys[r], kNone, __ATOMIC_RELAXED);   // zeroed above: free again
     }
 }
 
@@ -1639,16 +1555,10 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
     __shared__ __attribute__((aligned(16))) double s_rows[ROWS * STRIDE];
     __shared__ uint32_t s_keys[ROWS];
     __shared__ uint8_t s_touch[ROWS];
-#if RF_CACHE_REFCOUNT
-    __shared__ uint32_t s_refs[ROWS];
-#endif
     for (uint32_t i = threadIdx.x; i < (uint32_t)(ROWS * STRIDE); i += kBlock) s_rows[i] = 0.0;
     for (uint32_t i = threadIdx.x; i < (uint32_t)ROWS; i += kBlock) {
         s_keys[i] = kNone;
         s_touch[i] = (uint8_t)0;
-#if RF_CACHE_REFCOUNT
-        s_refs[i] = 0u;
-#endif
     }
     __syncthreads();
 
@@ -1662,14 +1572,6 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
     bool block_alive = true;
 #ifdef RF_EXPERIMENT_SECTIONS
     unsigned long long sec_cache = 0, sec_flush = 0, sec_steps = 0, sec_total = __builtin_readcyclecounter();
-#endif
-#if RF_CACHE_REFCOUNT
-#define RF_CACHE_GET(key) cache_acquire<ROWS>(s_keys, s_refs, (key))
-#define RF_CACHE_PUT(slot) atomicSub(&s_refs[(slot)], 1u)
-    constexpr uint32_t kQuarter = ((uint32_t)ROWS + 3u) / 4u;
-#else
-#define RF_CACHE_GET(key) cache_find<ROWS>(s_keys, (key))
-#define RF_CACHE_PUT(slot) ((void)0)
 #endif
     while (block_alive) {
         if (ballot(W.alive) != 0ull) {
@@ -1695,7 +1597,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
                     if constexpr (RF_ABSORB_STAGES > 1) absorb_stage<2, A>(lane, G.cur, act, v);
                     if constexpr (RF_ABSORB_STAGES > 2) absorb_stage<4, A>(lane, G.cur, act, v);
                     if constexpr (RF_ABSORB_STAGES > 3) absorb_stage<8, A>(lane, G.cur, act, v);
-                    const int s_row = act ? RF_CACHE_GET(G.cur) : -1;
+                    const int s_row = act ? cache_find<ROWS>(s_keys, G.cur) : -1;
                     if (act && s_row >= 0) {
                         s_touch[s_row] = (uint8_t)1;
                         double *row = s_rows + s_row * STRIDE;
@@ -1707,7 +1609,6 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
 #pragma unroll
                             for (int k = 0; k < 3 * NB; ++k) atomicAdd(row + k, (double)v[k]);
                         }
-                        RF_CACHE_PUT(s_row);
                     } else if (act) {
                         float *dst = p.attr_grad + (size_t)G.cur * p.attr_pitch;
 #pragma unroll
@@ -1715,25 +1616,23 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
                             if (v[k] != 0.0f) grad_add(dst + k, v[k]);
                     }
                 } else {
-                    const int s_row = act ? RF_CACHE_GET(G.cur) : -1;
+                    const int s_row = act ? cache_find<ROWS>(s_keys, G.cur) : -1;
                     if (act && s_row >= 0) {
                         s_touch[s_row] = (uint8_t)1;
                         atomicAdd(s_rows + s_row * STRIDE + L::COL_DS, (double)G.dL_ds);
-                        RF_CACHE_PUT(s_row);
                     } else if (act) {
                         grad_add(p.attr_grad + (size_t)G.cur * p.attr_pitch + (A - 1), G.dL_ds);
                     }
                 }
                 const bool pact = G.has && G.pg_on;
                 if (ballot(pact) != 0ull) {
-                    const int s_pg = pact ? RF_CACHE_GET(G.prev) : -1;
+                    const int s_pg = pact ? cache_find<ROWS>(s_keys, G.prev) : -1;
                     if (pact && s_pg >= 0) {
                         s_touch[s_pg] = (uint8_t)1;
                         double *dst = s_rows + s_pg * STRIDE + L::COL_PG;
                         atomicAdd(dst + 0, (double)G.px);
                         atomicAdd(dst + 1, (double)G.py);
                         atomicAdd(dst + 2, (double)G.pz);
-                        RF_CACHE_PUT(s_pg);
                     } else if (pact) {
                         float *dst = p.points_grad + 3 * (size_t)G.prev;
                         grad_add(dst + 0, G.px);
@@ -1750,28 +1649,6 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
 #endif
         }
         it++;
-#if RF_CACHE_REFCOUNT
-        block_alive = ballot(W.alive) != 0ull;          // this WAVE goes on by itself; the block meets once, at the end
-        if ((it & (kEpoch - 1u)) == 0u) {
-#ifdef RF_EXPERIMENT_SECTIONS
-            const unsigned long long f0 = __builtin_readcyclecounter();
-#endif
-            const uint32_t q = ((threadIdx.x >> 6) + (it / kEpoch)) & 3u;     // the quarter this wave sweeps this time
-            const uint32_t first = q * kQuarter;
-            const uint32_t count = first + kQuarter <= (uint32_t)ROWS ? kQuarter : (uint32_t)ROWS - first;
-            cache_sweep<NB>(s_rows, s_keys, s_refs, s_touch, first, count, false, p.attr_grad, p.points_grad, p.attr_pitch);
-#ifdef RF_EXPERIMENT_SECTIONS
-            sec_flush += __builtin_readcyclecounter() - f0;
-#endif
-        }
-    }
-    __syncthreads();                                    // every wave of the tile is done: what is left goes out
-    {
-        const uint32_t first = (threadIdx.x >> 6) * kQuarter;
-        const uint32_t count = first + kQuarter <= (uint32_t)ROWS ? kQuarter : (uint32_t)ROWS - first;
-        cache_sweep<NB>(s_rows, s_keys, s_refs, s_touch, first, count, true, p.attr_grad, p.points_grad, p.attr_pitch);
-    }
-#else
         if ((it & (kEpoch - 1u)) == 0u) {
 #ifdef RF_EXPERIMENT_SECTIONS
             const unsigned long long f0 = __builtin_readcyclecounter();
@@ -1784,9 +1661,6 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_BWD_WAVES : RF_BWD_WAVES_D3)
 #endif
         }
     }
-#endif
-#undef RF_CACHE_GET
-#undef RF_CACHE_PUT
 #ifdef RF_EXPERIMENT_SECTIONS
     // wave clocks per section: [8] waiting for the hop's records + face hit, [9] backward_segment, [10] merge + cache
     // updates of the step, [11] barriers + flush of the epochs, [12] the whole walk, [13] wave-steps

@@ -227,10 +227,11 @@ class Pipeline:
         #: image-shaped batches: the order in which the blocks of a launch take the 16x16 tiles (rf_launch_opts.tile_order),
         #: from the hop counts of the previous forward over a frame of this shape -- any order gives the same results, the
         #: order decides what is still running when a launch drains ("Work distribution"):
-        #:   "auto" (default)  forward: every XCD keeps the tiles the static dealing gives it but takes them longest first
-        #:                     (launches of at most 16384 blocks; larger ones as the backward); backward: the static order
-        #:                     with the cheapest 2048 tiles of the frame last; sorted flat batches (their 256-slot groups):
-        #:                     the cheapest eighth last in both launches;
+        #:   "auto" (default)  forward / render: for the very rays the order was learnt on (a frame traced again) every XCD
+        #:                     keeps the tiles the static dealing gives it but takes them longest first (launches of at
+        #:                     most 16384 blocks; larger ones as the backward), for new rays the static dealing; backward:
+        #:                     the static order with the cheapest 2048 tiles last, learnt by the forward of the same rays;
+        #:                     sorted flat batches (their 256-slot groups): the cheapest eighth last in both launches;
         #:   None / "static"   the static dealing of the kernels (strips of a quarter row per XCD, from both ends of the
         #:                     frame towards its middle);
         #:   "xcd", "tail", "tail:<count>", "global"   one rule for both launches (experiments).
@@ -636,7 +637,8 @@ class Pipeline:
         tiles_pending = None
         if opts.image_width:
             tiles_pending = self._tile_cost_begin(opts, opts.image_height, opts.image_width,
-                                                  (self._tkey(rays_c), self._tkey(start_c)), dev)
+                                                  (self._tkey(rays_c), self._tkey(start_c)), dev,
+                                                  backward_follows=trail is not None)
         elif opts.ray_order:
             tiles_pending = self._tile_cost_begin(opts, "flat", num_rays, (self._tkey(rays_c), self._tkey(start_c)), dev)
         with torch.cuda.device(dev):
@@ -671,16 +673,28 @@ class Pipeline:
         out["num_intersections"] = num_intersections
         return out
 
-    def _tile_cost_begin(self, opts, height, width, key, dev):
-        """Ask the launch about to be issued for the cost of its tiles (rf_launch_opts.tile_cost) when the tile orders of
-        this frame shape were learnt from other rays (another camera) or not at all.  Returns what _tile_cost_end needs."""
+    def _tile_cost_begin(self, opts, height, width, key, dev, backward_follows=False):
+        """Decide what this launch does about tile orders.  Returns what _tile_cost_end needs when the launch is to report
+        the cost of its tiles (rf_launch_opts.tile_cost), else None.
+
+        "auto" (measured on an asymmetric scene with a new camera every launch, profiles/r04/b_tile_order_asymmetric_*):
+        an order learnt on OTHER rays makes the forward and the render 2-6 % slower than the static dealing (the longest
+        tiles of another camera are not this camera's), while the backward's rule -- the cheapest tiles last -- still gains
+        2-6 % with it.  So a forward / render launch takes a learnt order only for the very rays it was learnt on (a frame
+        that is traced again: benchmark loops, evaluation of a fixed view), and learns -- for the trace_backward that
+        follows, and for a possible repeat -- whenever the rays are new and a backward will follow; without a backward
+        (renders) it learns every tile_order_refresh launches at most."""
         mode = self.tile_order_mode
         if mode in (None, "static") or (height != "flat" and (height < 16 or width < 16)):
             return None
         t = self._tile_sets.get((height, width))
         if t is not None and t["mode"] == mode and t["default"].device == dev:
             t["age"] += 1
-            if t["key"] == key or t["age"] < int(self.tile_order_refresh):
+            same = t["key"] == key
+            if mode == "auto" and not same and height != "flat":
+                opts.tile_order = None              # another camera's order: the static dealing is better for this launch
+            if same or (t["age"] < int(self.tile_order_refresh) and not (mode == "auto" and backward_follows and
+                                                                          height != "flat")):
                 return None
         tiles = (width + 255) // 256 if height == "flat" else ((height + 15) // 16) * ((width + 15) // 16)
         cost = torch.zeros(tiles, dtype=torch.int32, device=dev)

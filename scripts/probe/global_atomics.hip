@@ -26,6 +26,18 @@ __global__ __launch_bounds__(256) void scatter(float *buf, size_t n, size_t xcd_
             unsigned long long w = __shfl(x, 0, 64);
             const size_t base = (size_t)((w * 0x2545F4914F6CDD1Dull) >> 20) % (n - 256 * 28);
             unsafeAtomicAdd(buf + base + (a & 255) * 28 + 27, 1.0f);
+        } else if (MODE == 5 || MODE == 6) {
+            // gradient rows as the flat-batch backward sends them: one instruction = 48 lanes on one 192-byte row (3 lines);
+            // the rows of a block stay inside a 2 MB window (the wedge of the foam its rays cross) -- agent scope into
+            // the shared buffer (5) against workgroup scope into the XCD's private copy (6)
+            const unsigned long long w = __shfl(x, 0, 64);
+            const size_t win = (size_t)((blockIdx.x * 0x9E3779B97F4A7C15ull) >> 20) % (n - (1u << 19) - 64);
+            const size_t row = win + (((w * 0x2545F4914F6CDD1Dull) >> 20) % (1u << 13)) * 64;
+            const unsigned lane = threadIdx.x & 63u;
+            if (lane < 48u) {
+                if (MODE == 5) unsafeAtomicAdd(buf + row + lane, 1.0f);
+                else __hip_atomic_fetch_add(buf + xcc * xcd_stride + row + lane, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         } else if (MODE == 0) unsafeAtomicAdd(dst + a, 1.0f);
         else if (MODE == 1) __hip_atomic_fetch_add(dst + a, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_fetch_add(dst + a, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -52,12 +64,13 @@ void run(const char *name, size_t n) {
     const int blocks = 256 * 64;
     const size_t stride = n;
     float *buf, *red; double *tot;
-    hipMalloc(&buf, ((MODE == 1 || MODE == 2) ? 8 : 1) * n * sizeof(float));
+    constexpr bool kPerXcd = MODE == 1 || MODE == 2 || MODE == 6;
+    hipMalloc(&buf, (kPerXcd ? 8 : 1) * n * sizeof(float));
     hipMalloc(&red, n * sizeof(float));
     hipMalloc(&tot, 8);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int rep = 0; rep < 2; ++rep) {
-        hipMemset(buf, 0, ((MODE == 1 || MODE == 2) ? 8 : 1) * n * sizeof(float));
+        hipMemset(buf, 0, (kPerXcd ? 8 : 1) * n * sizeof(float));
         hipMemset(tot, 0, 8);
         hipDeviceSynchronize();
         hipEventRecord(a);
@@ -67,10 +80,10 @@ void run(const char *name, size_t n) {
     }
     float ms; hipEventElapsedTime(&ms, a, b);
     const float *res = buf;
-    if (MODE == 1 || MODE == 2) { reduce8<<<(unsigned)((n + 255) / 256), 256>>>(buf, n, stride, red); res = red; }
+    if (kPerXcd) { reduce8<<<(unsigned)((n + 255) / 256), 256>>>(buf, n, stride, red); res = red; }
     total<<<1024, 256>>>(res, n, tot);
     double h; hipMemcpy(&h, tot, 8, hipMemcpyDeviceToHost);
-    const double ops = (double)blocks * 256 * kPerLane;
+    const double ops = (double)blocks * 256 * kPerLane * ((MODE == 5 || MODE == 6) ? 48.0 / 64.0 : 1.0);
     printf("%-46s %8.3f ms  %7.2f G atomics/s   sum %.0f expected %.0f %s\n", name, ms, ops / ms / 1e6, h, ops,
            h == ops ? "OK" : "LOST UPDATES");
     hipFree(buf); hipFree(red); hipFree(tot);
@@ -85,6 +98,8 @@ int main() {
         run<2>("wavefront scope, buffer per XCD", n);
         run<3>("agent scope, wave hits a moving 1 KB window", n);
         run<4>("agent scope, 112-B rows near a moving window", n);
+        run<5>("agent scope, 192-B rows (48 lanes), 2 MB window/block", n);
+        run<6>("workgroup scope per XCD, 192-B rows, 2 MB window", n);
     }
     return 0;
 }
