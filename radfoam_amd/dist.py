@@ -15,7 +15,7 @@ largest BASELINE config) is replicated on every GPU; a batch of rays shaped [H, 
   * the row blocks of ONE image touch nearly disjoint wedges of the foam, so each rank's dense buffer
     is almost all zeros: ``SparseGradExchange`` all-gathers only the rows that hold anything (a few MB
     per rank) and adds them in rank order -- bit-identical sums on every rank at a fraction of the
-    dense all-reduce's xGMI traffic (DESIGN.md section 5 has the arithmetic);
+    dense all-reduce's xGMI traffic (DESIGN.md section 7 has the arithmetic);
   * rays through different parts of a frame walk very different numbers of cells, so equal row counts
     are not equal work: ``balanced_row_blocks`` cuts the rows by measured cost (the previous step's
     ``num_intersections``).
@@ -186,6 +186,9 @@ class SparseGradExchange:
 
     def _compact(self, points_grad, attr_grad, send, count):
         n, a = attr_grad.shape
+        if not attr_grad.is_contiguous():
+            raise RuntimeError("SparseGradExchange needs the dense [N, A] gradient rows: set "
+                               "pipeline.gradient_row_pitch = 'dense' (ShardedTracer does)")
         if points_grad.is_cuda:
             from . import _lib
             lib = _lib.load()

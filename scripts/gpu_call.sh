@@ -1,22 +1,35 @@
 # the batch of one gpurun call (rewritten per call; what each call ran is recorded in profiles/README.md)
-cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4d; mkdir -p $O
-L=$GRAFT_REPO_ROOT/radfoam_amd
-for v in base td; do
-  lib=$L/libradfoam_hip.so; [ $v = td ] && lib=$L/libradfoam_hip_td.so
-  (RADFOAM_HIP_LIB=$lib timeout 300 python scripts/gpu_delaunay.py 2000000 5 2>&1 | tail -1) > $O/delaunay_$v.json; cat $O/delaunay_$v.json
-done
-(RADFOAM_HIP_LIB=$L/libradfoam_hip_refc.so timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "backward or frame or tile_order or trail or strict" 2>&1 | tail -5) > $O/pytest_refc.log; tail -2 $O/pytest_refc.log
-for v in base base156 refc refc8 refc2; do
-  lib=$L/libradfoam_hip_$v.so; [ $v = base ] && lib=$L/libradfoam_hip.so
-  for w in north-star c2; do
-    RADFOAM_HIP_LIB=$lib timeout 400 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads 2>/dev/null | tail -1 > $O/${v}_$w.json
-    python - $v $w $O/${v}_$w.json <<'PY'
-import json,sys
-try:
-    d=json.load(open(sys.argv[3])); print(sys.argv[1], sys.argv[2], 'Mrays/s', d['value'], 'fwd', d['detail']['forward_ms'], 'bwd', d['detail']['backward_ms'])
-except Exception as e: print(sys.argv[1], sys.argv[2], 'failed', e)
-PY
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r4e; mkdir -p $O
+cd $R
+(timeout 900 python scripts/gpu_shard_sim.py 2>&1 | tail -30) > $O/shard_simulation_one_gpu.log; tail -6 $O/shard_simulation_one_gpu.log
+cp gpurun_out/shard_sim*.json $O/ 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+for m in static auto prev; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_tile_$m/$C -o run -- python $R/scripts/gpu_tile_order_asymmetric.py --mode $m > $O/pmc_tile_${m}_$C.log 2>&1
   done
 done
-(timeout 600 python scripts/gpu_tile_order_asymmetric.py 2>&1 | tail -1) > $O/tile_order_asymmetric.json; cat $O/tile_order_asymmetric.json
+cd $R
+python - <<'PY'
+import csv, glob, collections, json, os, re
+O = "gpurun_out/r4e"
+out = {}
+for m in ("static", "auto", "prev"):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{O}/pmc_tile_{m}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = re.search(r"rf::(\w+)", r["Kernel_Name"])
+            if not k or "stats" in r["Kernel_Name"]:
+                continue
+            name = k.group(1)
+            if name == "forward_kernel":
+                name = "render" if re.search(r"forward_kernel<\d, true, true", r["Kernel_Name"]) else "forward"
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out[m] = {k: {"launches": max(len(v) for v in c.values()),
+                  "hbm_GB_per_launch": round((2 * sum(c.get("FETCH_SIZE", [0])) / max(len(c.get("FETCH_SIZE", [1])), 1) +
+                                              sum(c.get("WRITE_SIZE", [0])) / max(len(c.get("WRITE_SIZE", [1])), 1)) * 1024 / 1e9, 3)}
+              for k, c in agg.items() if k in ("forward", "render", "backward_replay_cached_kernel")}
+json.dump(out, open(f"{O}/tile_order_asymmetric_hbm.json", "w"), indent=1)
+print(json.dumps(out))
+PY

@@ -28,6 +28,11 @@ if has configs; then
   (timeout 900 python bench.py --quantiles 2 --steps 10 --warmup 3 2>$O/bench_ns_q2.err | tail -1) > $O/bench_ns_q2.json
   (timeout 900 python bench.py --workload train-batch --quantiles 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1) > $O/bench_train-batch_q2.json
   (timeout 900 python bench.py --workload train-batch --sh-degree 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1) > $O/bench_train-batch_sh2.json
+  # every segment lit (what the scene's softplus gives: real training), the reference's quotient scan, and the loop itself
+  (timeout 900 python bench.py --workload train-batch --empty-density 4.5e-6 --steps 10 --warmup 3 2>$O/bench_train-batch_alllit.err | tail -1) > $O/bench_train-batch_alllit.json
+  (timeout 900 python bench.py --strict-scan --steps 10 --warmup 3 2>$O/bench_ns_strict.err | tail -1) > $O/bench_ns_strict.json
+  (timeout 900 python bench.py --workload train-loop 2>$O/bench_train-loop.err | tail -1) > $O/bench_train-loop.json
+  [ -x scripts/probe/global_atomics ] && (timeout 120 scripts/probe/global_atomics > $O/probe_global_atomics.log 2>&1)
 fi
 cd /tmp && export TMPDIR=/tmp
 PMCW="${PMC_WORKLOADS:-north-star c2 c5 render train-batch}"

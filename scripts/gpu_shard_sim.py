@@ -57,6 +57,7 @@ g = torch.randn(rays.shape[:-1] + (4,), generator=torch.Generator().manual_seed(
 pipe = radfoam.create_pipeline(d)
 pipe.record_trail = not args.forward_only
 pipe.forward_mode = args.forward_mode
+pipe.gradient_row_pitch = "dense"   # the exchange kernels read the reference's dense [N][A] rows (ShardedTracer sets this)
 A = pipe.attribute_dim()
 n = p.shape[0]
 ev = lambda: torch.cuda.Event(enable_timing=True)

@@ -68,6 +68,12 @@ for f in sorted(glob.glob(os.path.join(d, "bench*.json"))):
         det = b["detail"]
         print(os.path.basename(f), b["value"], b["unit"], "| ms/step", b["ms_per_step"], "fwd", det.get("forward_ms"), "bwd",
               det.get("backward_ms"), "pack", det.get("foam_pack_ms"), "| n_gpus", b["n_gpus"], b["scaling"])
+        if "ms_per_iteration" in det:
+            print("   loop:", det["ms_per_iteration"], det.get("rebuilds"), det.get("densification"))
+        for name, o in (b.get("other_workloads") or {}).items():
+            print("   other:", name, {k: o.get(k) for k in ("value", "forward_ms", "backward_ms", "matches_gpu_bitwise",
+                                                            "points_grad_rel_l2", "attr_grad_rel_l2", "seconds", "error")},
+                  (o.get("roofline") or {}).get("bound"), (o.get("roofline") or {}).get("frac"))
         r = b.get("roofline")
         if r:
             print("   roofline:", {k: r[k] for k in ("bound", "kernel", "frac", "traffic", "algorithmic_GBps")}, r["hbm"])

@@ -62,4 +62,9 @@ for f in sorted(glob.glob(os.path.join(ev, "counters_*.json"))):
         "kernels": {k: v for k, v in json.load(open(f)).items() if "[stats]" not in k},
     }
 json.dump(allc, open(cj, "w"), indent=1)
+for extra in ("probe_global_atomics.log",):
+    keep(os.path.join(ev, extra), extra)
+# the ISA constants bench.py's useful_valu_frac rests on, from the same sources (no GPU needed: hipcc -S)
+import subprocess
+subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "isa_stats.py"), "--constants"], check=False)
 print("kept under profiles/%s:" % rnd, *kept, sep="\n  ")
