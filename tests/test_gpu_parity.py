@@ -948,3 +948,37 @@ def test_strict_reference_scan_instance(foam_factory, d, image, quantiles):
     pipe.trace_benchmark(p, a, adj, off, dtab, camera, sp, img, weight_threshold=0.05)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(img.cpu().numpy().view(np.uint32), bench_ref)
+
+
+@pytest.mark.parametrize("d,image", [(1, True), (2, False), (3, False), (3, True)])
+def test_gradient_row_pitch_does_not_change_the_gradients(foam_factory, d, image):
+    """Pipeline.gradient_row_pitch / rf_launch_opts.attr_grad_pitch: "auto" accumulates attr_grad in rows on 64-byte lines
+    (16 / 32 / 64 floats for A = 13 / 28 / 49) and returns a [N, A] VIEW of them, "dense" is the reference's contiguous
+    [N, A], an int any pitch >= A -- same gradients (vs the oracle) whichever; the padding columns stay zero; a pitch below
+    A is refused."""
+    fm, rays, starts, q, dg, g, err, fwd, ref = _backward_case(foam_factory, d, 70 + d, image, False, False)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    t = lambda x: None if x is None else torch.from_numpy(x).to(DEV)
+    A = fm["attributes"].shape[1]
+    for pitch in ("auto", "dense", A + 3):
+        pipe = _pipeline(d)
+        pipe.gradient_row_pitch = pitch
+        f = pipe.trace_forward(p, a, adj, off, t(rays), t(starts))
+        out = pipe.trace_backward(p, a, adj, off, t(rays), t(starts), f["rgba"], t(g))
+        torch.cuda.synchronize()
+        ag = out["attr_grad"]
+        assert ag.shape == (fm["points"].shape[0], A)
+        want_pitch = {"auto": {4: 4, 13: 16, 28: 32, 49: 64}[A], "dense": A}.get(pitch, pitch)
+        assert ag.stride() == (want_pitch, 1) and ag.is_contiguous() == (want_pitch == A)
+        for key in ("points_grad", "attr_grad"):
+            ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+            assert ok and rel < 1e-5, (pitch, key, rel, worst)
+        if want_pitch != A:      # what lies between the rows was never written
+            n = fm["points"].shape[0]
+            rows = out["flat_grad"][-n * want_pitch:].view(n, want_pitch)
+            assert rows.data_ptr() == ag.data_ptr() and float(rows[:, A:].abs().max()) == 0.0
+            assert ag.data_ptr() % 64 == 0
+    bad = _pipeline(d)
+    bad.gradient_row_pitch = A - 1
+    with pytest.raises(RuntimeError, match="gradient_row_pitch"):
+        bad.trace_backward(p, a, adj, off, t(rays), t(starts), t(fwd["rgba"]), t(g))
