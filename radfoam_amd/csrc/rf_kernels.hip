@@ -386,6 +386,10 @@ __device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uin
     ScanResult r;
     r.t1 = __builtin_inff();
     r.k = kNone;
+    const v2f half2 = {0.5f, 0.5f};
+    const v2f P2x = {Px, Px}, P2y = {Py, Py}, P2z = {Pz, Pz};
+    const v2f O2x = {Ox, Ox}, O2y = {Oy, Oy}, O2z = {Oz, Oz};
+    const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
     const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
     for (uint32_t k = 0; k < cnt; k += 4) {
         GeoXY A;
@@ -393,19 +397,25 @@ __device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uin
         load_geo_block(src, A, B);
         src += 6;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t wx = j < 2 ? A.x01 : A.x23, wy = j < 2 ? A.y01 : A.y23, wz = j < 2 ? B.z01 : B.z23;
-            const float ox = (j & 1) ? half_hi(wx) : half_lo(wx);
-            const float oy = (j & 1) ? half_hi(wy) : half_lo(wy);
-            const float oz = (j & 1) ? half_hi(wz) : half_lo(wz);
-            const float dp = dot3(ox, oy, oz, dx, dy, dz);
-            const float vx = (Px + ox * 0.5f) - Ox;
-            const float vy = (Py + oy * 0.5f) - Oy;
-            const float vz = (Pz + oz * 0.5f) - Oz;
-            const float t = dot3(vx, vy, vz, ox, oy, oz) / dp;
-            const bool take = (dp > 0.0f) & (t < r.t1);
-            r.t1 = take ? t : r.t1;
-            r.k = take ? k + (uint32_t)j : r.k;
+        for (int h = 0; h < 2; ++h) {
+            // two faces per packed instruction up to the quotients (the same roundings as the scalar form: every packed
+            // lane is an independent IEEE operation); the divides and the running minimum stay per face, in list order
+            const uint32_t wx = h ? A.x23 : A.x01, wy = h ? A.y23 : A.y01, wz = h ? B.z23 : B.z01;
+            const v2f ox = {half_lo(wx), half_hi(wx)};
+            const v2f oy = {half_lo(wy), half_hi(wy)};
+            const v2f oz = {half_lo(wz), half_hi(wz)};
+            const v2f dpp = fma2(ox, d2x, fma2(oy, d2y, oz * d2z));
+            const v2f vx = (P2x + ox * half2) - O2x;
+            const v2f vy = (P2y + oy * half2) - O2y;
+            const v2f vz = (P2z + oz * half2) - O2z;
+            const v2f num = fma2(vx, ox, fma2(vy, oy, vz * oz));
+            const float t0 = num.x / dpp.x, t1 = num.y / dpp.y;
+            const bool take0 = (dpp.x > 0.0f) & (t0 < r.t1);
+            r.t1 = take0 ? t0 : r.t1;
+            r.k = take0 ? k + (uint32_t)(2 * h) : r.k;
+            const bool take1 = (dpp.y > 0.0f) & (t1 < r.t1);
+            r.t1 = take1 ? t1 : r.t1;
+            r.k = take1 ? k + (uint32_t)(2 * h + 1) : r.k;
         }
     }
     return r;
@@ -1806,6 +1816,9 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
             // colour rows: stage lane-major, emit column-major (two rows per pass, a lane per column)
             const bool lit = G.has && G.row;
             if constexpr (FROM_BASIS) {
+                // (Measured out in round 4, profiles/r04/e_row_emission_pipelined_ab.log: the members of all groups in ONE
+                // loop with the next member's basis value requested before this one's is used -- 5.05 against 5.00 ms, the
+                // wait counter at the loop's back edge makes the compiler wait for the early read anyway.)
                 unsigned long long todo = ballot(lit);
                 const uint32_t bcol = lane / 3u, ccol = lane - 3u * bcol;   // column `lane` = basis bcol, channel ccol
                 while (todo != 0ull) {

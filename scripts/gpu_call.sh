@@ -1,14 +1,14 @@
 # the batch of one gpurun call (rewritten per call; what each call ran is recorded in profiles/README.md)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4f; mkdir -p $O
-(timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -30) > $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
-(timeout 900 python bench.py --steps 20 --warmup 5 2>$O/bench.err | tail -1) > $O/bench.json
-(timeout 300 python scripts/gpu_tile_order_asymmetric.py 2>/dev/null | tail -1) > $O/tile_order_asymmetric_new_policy.json
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/r4f/bench.json")); r=d["roofline"]
-print(d["value"], {k:r[k] for k in ("bound","frac","traffic","counters_stale","useful_valu_frac","useful_scan_valu_frac")}, r["isa_constants"])
-for k,v in d["other_workloads"].items(): print(k, v.get("value"), v.get("matches_gpu_bitwise"), v.get("roofline",{}).get("bound"), v.get("roofline",{}).get("frac"), v.get("seconds"), v.get("error"))
-t=json.load(open("gpurun_out/r4f/tile_order_asymmetric_new_policy.json"))
-for m,r in t["result"].items(): print(m, {k:v["mean_ms"] for k,v in r.items() if isinstance(v,dict)})
-PY
+O=gpurun_out/r4h; mkdir -p $O
+(timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "backward_parity or pitch or strict" 2>&1 | tail -3) > $O/pytest.log; tail -1 $O/pytest.log
+run() { n=$1; lib=$2; shift 2
+  RADFOAM_HIP_LIB=$GRAFT_REPO_ROOT/radfoam_amd/$lib timeout 400 python bench.py --workload train-batch --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads "$@" 2>/dev/null | tail -1 > $O/$n.json
+  python -c "
+import json; d=json.load(open('$O/$n.json')); print('$n', d['value'], d['detail']['forward_ms'], d['detail']['backward_ms'])"; }
+for rep in 1 2; do
+run pipe_sparse_$rep libradfoam_hip.so
+run prev_sparse_$rep libradfoam_hip_prev.so
+done
+run pipe_alllit libradfoam_hip.so --empty-density 4.5e-6
+run prev_alllit libradfoam_hip_prev.so --empty-density 4.5e-6

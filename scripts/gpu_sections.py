@@ -18,6 +18,10 @@ dev = torch.device("cuda:0")
 workload = os.environ.get("WORKLOAD", "train-batch")
 sh = int(os.environ.get("SH", "3" if workload == "train-batch" else "2"))
 fm = foam.make_synthetic_foam(2_000_000, sh, 5, cache_dir=foam.default_cache_dir())
+if os.environ.get("EMPTY_DENSITY"):     # every segment lit: bench.py --empty-density
+    fm = dict(fm)
+    fm["attributes"] = fm["attributes"].copy()
+    fm["attributes"][:, -1] = np.maximum(fm["attributes"][:, -1], np.float32(os.environ["EMPTY_DENSITY"]))
 if workload == "train-batch":
     rays_np, start_np = bench.training_batch(fm, 1_000_000, 105)
 else:
@@ -45,7 +49,7 @@ torch.cuda.synchronize()
 s = stats.cpu().tolist()
 tot = s[12]
 third, fourth = ("tables", "colour_rows_out") if workload == "train-batch" else ("merge_and_cache_updates", "epoch_barriers_and_flush")
-print(json.dumps({"workload": workload, "sh_degree": sh, "backward_ms": round(e0.elapsed_time(e1), 3), "wave_steps": s[13],
+print(json.dumps({"workload": workload, "sh_degree": sh, "empty_density": os.environ.get("EMPTY_DENSITY"), "backward_ms": round(e0.elapsed_time(e1), 3), "wave_steps": s[13],
                   "clocks_per_wave_step": round(tot / max(s[13], 1), 1),
                   "share_wait_records_and_face_hit": round(s[8] / tot, 3), "share_segment_colour_row_and_math": round(s[9] / tot, 3),
                   "share_" + third: round(s[10] / tot, 3), "share_" + fourth: round(s[11] / tot, 3),
