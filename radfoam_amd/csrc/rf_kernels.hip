@@ -1756,7 +1756,11 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
     // steps, which tied the waves of a block into lockstep -- twelve waves per CU hid latency like three (the launch
     // ran 6.1 ms of its 9.9 with every global atomic compiled out).  A block's rays meet a cell about ten times
     // (scripts/model_train_batch.py), so the tables remove nearly all of these requests.
-    constexpr int DROWS = RF_DTABLE_ROWS;
+    // 768 entries per table where four blocks share a CU (SH degree <= 2: 14 KB of staging + 24.6 KB of tables); 1024 at
+    // degree 3, whose three blocks per CU have the room since the rows are rebuilt from the basis (16 KB + 32 KB): backward
+    // of the training batch 5.04 -> 4.89 ms, every segment lit 14.97 -> 14.54; 512: 5.25 / 15.7; 1152: as 1024
+    // (profiles/r04/i_table_rows_ab.log)
+    constexpr int DROWS = DEG >= 3 ? (RF_DTABLE_ROWS > 1024 ? RF_DTABLE_ROWS : 1024) : RF_DTABLE_ROWS;
     __shared__ unsigned long long s_tab[4][DROWS];
     for (uint32_t e = threadIdx.x; e < (uint32_t)(4 * DROWS); e += kBlock) (&s_tab[0][0])[e] = kEmptyEntry;
     __syncthreads();
