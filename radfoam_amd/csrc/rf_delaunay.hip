@@ -169,7 +169,15 @@ __global__ __launch_bounds__(64, WAVES_PER_SIMD) void delaunay_star_kernel(
     const star::Tree tr{tree, n, depth};
     const star::HullSet first_pass{nullptr, 0u, budget};
     uint32_t visited = 0, inserted = 0;
+#if RF_STAR_KNN_SEEDS > 0
+    // a star without a previous list is seeded with its K nearest points from a walk of the tree (rf_star.hpp:
+    // RF_STAR_KNN_SEEDS) instead of the nearest of its 64-point kd-block
+    int ns_used = ns;
+    if (!seed_adj) ns_used = star::star_knn_up<RF_STAR_KNN_SEEDS>(tr, pts, i, seeds, visited);
+    star::star_build(s, tr, pts, first_pass, seeds, ns_used, visited, inserted);
+#else
     star::star_build(s, tr, pts, first_pass, seeds, ns, visited, inserted);
+#endif
     atomicAdd(&counters->inserted, inserted);
     const uint32_t old = atomicAdd(&counters->nodes_lo, visited);
     if (old + visited < old) atomicAdd(&counters->nodes_hi, 1u);

@@ -839,6 +839,86 @@ RF_STAR_FN uint32_t star_search(S &s, const Tree &tr, const float *pts, int t, c
     return best_id;
 }
 
+// Seeds of a star that has no previous neighbour list (a from-scratch build): its RF_STAR_KNN_SEEDS nearest points from a
+// walk of the tree; 0 = the nearest 12 of its 64-point block of the kd-order (rounds 2-3).  Measured (2 M / 500 k points
+// from scratch, profiles/r04/k_delaunay_knn_seeds_ab.log): block seeds 340 / 110.5 ms, 2099 / 1966 tree nodes per point;
+// 12 tree neighbours 318 / 108.7 ms, 2031 / 1896 nodes, 15.1 instead of 17.1 insertions per point; 16: 338 / 105.7; 24
+// (what the owner-certified prototype of round 3 used): 372 / 111.1 -- every seed is inserted, and half of 24 are not
+// Delaunay neighbours.  Seeds never decide the result.
+#ifndef RF_STAR_KNN_SEEDS
+#define RF_STAR_KNN_SEEDS 12
+#endif
+
+// The K nearest points of p_self (nearest first), for the seeds of a star that has no previous neighbour list: the same
+// bottom-up walk as star_search -- p_self's bucket, then the sibling subtree of every ancestor, one flat loop -- with a
+// box entered only while it is nearer than the K-th candidate so far.  Returns the number found (K unless n <= K).
+template <int K>
+RF_STAR_FN int star_knn_up(const Tree &tr, const float *pts, uint32_t self, uint32_t *out, uint32_t &visited) {
+    const float px = pts[3 * (size_t)self], py = pts[3 * (size_t)self + 1], pz = pts[3 * (size_t)self + 2];
+    float bd[K];
+    int n = 0;
+    const uint32_t leaf_depth = tr.depth - kLeafBits;
+    uint32_t d0 = leaf_depth, k0 = self >> kLeafBits;        // the subtree being walked: p_self's bucket first
+    uint32_t next = leaf_depth;                              // then the sibling of the ancestor at this level, upwards
+    uint32_t ld = 0, vidx = 0, flip = 0;
+    for (;;) {
+        const uint32_t depth = d0 + ld;
+        const uint32_t idx = (k0 << ld) | (vidx ^ flip);
+        const uint32_t first = idx << (tr.depth - depth);
+        bool descend = false;
+        if (first < tr.n) {
+            const float *nd = tree_node(tr, depth, idx);
+            ++visited;
+            if (n < K || box_dist2(nd, px, py, pz) < bd[K - 1]) {
+                if (depth < leaf_depth) {
+                    descend = true;
+                } else {
+                    const uint32_t end = first + (1u << kLeafBits) < tr.n ? first + (1u << kLeafBits) : tr.n;
+                    for (uint32_t j = first; j < end; ++j) {
+                        if (j == self) continue;
+                        const float dx = pts[3 * (size_t)j] - px, dy = pts[3 * (size_t)j + 1] - py;
+                        const float dz = pts[3 * (size_t)j + 2] - pz;
+                        const float d = dx * dx + dy * dy + dz * dz;
+                        if (n == K && !(d < bd[K - 1])) continue;
+                        int pos = n < K ? n++ : K - 1;       // sorted insertion, nearest first
+                        while (pos > 0 && bd[pos - 1] > d) {
+                            bd[pos] = bd[pos - 1];
+                            out[pos] = out[pos - 1];
+                            --pos;
+                        }
+                        bd[pos] = d;
+                        out[pos] = j;
+                    }
+                }
+            }
+        }
+        if (descend) {
+            const uint32_t dim = depth % 3;
+            const float *left = tree_node(tr, depth + 1, 2 * idx);
+            const float pd = dim == 0 ? px : (dim == 1 ? py : pz);
+            const uint32_t right_first = pd > left[3 + dim] ? 1u : 0u;
+            ++ld;
+            vidx <<= 1;
+            flip = (flip << 1) | right_first;
+            continue;
+        }
+        ++vidx;
+        uint32_t up = (uint32_t)__builtin_ctz(vidx);
+        up = up < ld ? up : ld;
+        ld -= up;
+        vidx >>= up;
+        flip >>= up;
+        if (ld == 0) {
+            if (next == 0u) break;
+            d0 = next;
+            k0 = (self >> (tr.depth - d0)) ^ 1u;
+            --next;
+            vidx = flip = 0;
+        }
+    }
+    return n;
+}
+
 // Starting tetrahedron: the first seed triple that is not coplanar with p_i.  Sets kDegenerate if there is none.
 template <typename S>
 RF_STAR_FN void star_first_tet(S &s, const float *pts, const uint32_t *seeds, int nseeds, int *used) {

@@ -61,6 +61,8 @@ static int one_star(const float *pts, uint32_t n, const Tree &tr, const HullSet 
     }
     uint32_t vis = 0, ins = 0;
     const auto t0 = std::chrono::steady_clock::now();
+    // as delaunay_star_kernel: a star without a previous list takes its seeds from a walk of the tree
+    if (!old_adj && RF_STAR_KNN_SEEDS > 0) ns = star_knn_up<(RF_STAR_KNN_SEEDS > 0 ? RF_STAR_KNN_SEEDS : 1)>(tr, pts, i, seeds, vis);
     star_build(s, tr, pts, hull, seeds, ns, vis, ins);
     g_star_ns[i] += (uint32_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     visited[i] += vis;
