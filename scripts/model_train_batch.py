@@ -106,7 +106,7 @@ def simulate_row_cache(cells, n, lit):
     its own cell)."""
     pos = np.zeros(256, dtype=np.int64)
     alive = pos < n
-    ks, ss = (64, 128, 256), (32, 64, 128)
+    ks, ss = (64, 128, 256), (8, 16, 32, 64, 128)
     lru = {k: collections.OrderedDict() for k in ks}
     miss = {k: 0 for k in ks}
     dm = {s: [np.full(s, -1, dtype=np.int64) for _ in range(4)] for s in ss}
