@@ -137,6 +137,8 @@ def parse_args(argv=None):
                     help="Pipeline.strict_reference_scan: the reference's per-face quotient scan (tracing_utils.cuh:43-67, "
                          "rf_launch_opts.forward_mode 3) in forward, backward and render; the CPU baseline then runs the "
                          "oracle in its 'reference' scan mode, so that the bitwise comparison still holds")
+    ap.add_argument("--forward-mode", type=int, default=None,
+                    help="Pipeline.forward_mode (experiments): 1 blocks, 2 eager, 3 = --strict-scan, 4 persistent waves with refill")
     ap.add_argument("--grad-pitch", default=None, help="Pipeline.gradient_row_pitch: auto (default), dense, or floats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",
@@ -450,6 +452,8 @@ def run_workload(args, W, env):
         pipe.record_trail = not W["forward_only"]   # trace_backward is driven by hand on plain tensors
         if args.tile_order is not None:
             pipe.tile_order_mode = None if args.tile_order == "static" else args.tile_order
+        if args.forward_mode is not None:
+            pipe.forward_mode = args.forward_mode
         if args.strict_scan:
             pipe.strict_reference_scan = True
             W["custom"] = True

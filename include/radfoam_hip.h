@@ -99,6 +99,8 @@ typedef struct rf_launch_opts {
                               /*   the reference's tie-breaking at near-ties; slower (a correctly rounded divide per      */
                               /*   face).  rf_trace_backward and rf_trace_benchmark honour 3 as well (the replay of a     */
                               /*   trail must be given the mode its forward ran in); they ignore 0..2.                    */
+                              /*   4 (rf_trace_forward, experiment) = persistent waves that refill their dead lanes from  */
+                              /*   a queue by ballot + prefix count -- same results, slower on every workload measured    */
     /* Optional: device uint32[rf_launch_blocks(...)], the tile each block of the launch walks -- a 16x16-pixel tile of   */
     /* an image-shaped batch, a group of 256 consecutive thread slots of a flat one (values >= the number of tiles: the   */
     /* block owns no rays).  It MUST name every tile exactly once; the library does not check it (the table lives on the */

@@ -85,6 +85,7 @@ struct FwdParams {
     uint32_t *trail;        // [trail_cap][trail_slots] cell entered by each hop (optional)
     uint32_t *trail_hops;   // [trail_slots] hops taken by the ray of each thread slot
     uint32_t trail_cap, trail_slots;
+    uint32_t *queue;        // forward_mode 4: one device uint32 (the persistent waves' ray queue head), in the workspace
     // benchmark
     rf_camera cam;
     float inv_tan_half_fov;
@@ -173,11 +174,12 @@ inline uint32_t launch_blocks(const RayGrid &g) {
     return (nt + round - 1u) / round * round;
 }
 
-// ray and trail slot of this thread; false when it owns no ray (slot == kNone: not even a slot)
-__device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray, uint32_t &slot) {
+// ray and trail slot of thread `tid` of block `block` of a launch of `nblocks` blocks; false when it owns no ray (slot ==
+// kNone: not even a slot)
+__device__ __forceinline__ bool map_slot(const RayGrid &g, uint32_t block, uint32_t tid, uint32_t nblocks, uint32_t &ray,
+                                         uint32_t &slot) {
     const uint32_t chunk = tile_chunk(g);
-    const uint32_t tile = g.tile_order ? g.tile_order[blockIdx.x] : dealt_tile(blockIdx.x, chunk, gridDim.x / (8u * chunk));
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = g.tile_order ? g.tile_order[block] : dealt_tile(block, chunk, nblocks / (8u * chunk));
     ray = 0;
     slot = kNone;
     if (tile >= num_tiles(g)) return false;
@@ -198,6 +200,10 @@ __device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray, uint32_
     if (slot >= g.num_rays) return false;
     ray = g.order ? g.order[slot] : slot;
     return true;
+}
+
+__device__ __forceinline__ bool map_ray(const RayGrid &g, uint32_t &ray, uint32_t &slot) {
+    return map_slot(g, blockIdx.x, threadIdx.x, gridDim.x, ray, slot);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -783,6 +789,171 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
             atomicAdd(p.stats + 4, st_lit);
             if (lane == 0) atomicAdd(p.stats + 6, (unsigned long long)wave_steps);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent waves with refill (rf_launch_opts.forward_mode = 4; experiment): the north star's third mechanism --
+// "wavefront ballot / prefix-sum used to compact active rays as transmittance falls off".  A launch is as many blocks as
+// the chip holds at once; a wave keeps walking, and whenever at most RF_REFILL_BELOW of its lanes are still alive the dead
+// ones write their ray's outputs and take new rays from a global queue -- ONE atomicAdd for the wave (the ballot counts
+// the dead lanes, the prefix count of the ballot ranks them), in the order the ordinary launch would have taken them
+// (slot q = block q / 256, thread q % 256 of that launch), so the trail slots, the tile orders and every output are the
+// same.  Live lanes keep their state in registers: nothing is moved, the wave is simply full again.  Results are per ray
+// and do not depend on which lane walked it (bit-identical: tests/test_gpu_parity.py runs this mode too).
+// Measured (profiles/r04/l_persistent_refill_ab.log; forward of the 1080p frame / of the training batch, ms): the ordinary
+// launch 4.46 / 4.34; refilling when at most 0 / 16 / 32 / 48 / 56 / 63 lanes are alive 4.97 / 5.61 / 5.85 / 6.22 / 7.10 / 12.6 and
+// 5.10 / 5.33 / 5.59 / 5.98 / 6.50 / 8.80 -- the more a wave refills, the slower: 92.8 % (87.7 %) of its lane-steps are live
+// anyway, a refilled lane's ray comes from another tile (other cells, other cache lines), and the refill itself (ray load,
+// SH basis, start cell) runs with most of the wave masked off.  Kept as a tested experiment mode; never picked by mode 0.
+#ifndef RF_REFILL_BELOW
+#define RF_REFILL_BELOW 16
+#endif
+#ifndef RF_PERSISTENT_WAVES
+#define RF_PERSISTENT_WAVES 5
+#endif
+
+template <int DEG, bool HALF>
+__global__ __launch_bounds__(kBlock, (DEG <= 2 ? RF_PERSISTENT_WAVES : 4)) void forward_persistent_kernel(
+    FwdParams p, uint32_t *__restrict__ queue, uint32_t queue_blocks) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const FoamView &fv = p.foam;
+    const uint32_t total = queue_blocks * (uint32_t)kBlock;
+    const float thr = p.settings.weight_threshold;
+    const uint32_t max_steps = p.settings.max_intersections;
+
+    bool alive = false, valid = false;
+    uint32_t ray = 0, slot = kNone, cur = 0, n = 0, hops = 0, nb = 0, cnt = 0;
+    float Ox = 0.0f, Oy = 0.0f, Oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 1.0f;
+    float sh[sh_dim(DEG)];
+    sh_basis<DEG>(dx, dy, dz, sh);
+    float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, t0 = 0.0f;
+    float4 head = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool more = true;      // wave-uniform: the queue may still hold rays
+
+    for (;;) {
+        unsigned long long live = ballot(alive);
+        if (more && __builtin_popcountll(live) <= RF_REFILL_BELOW) {
+            // ---- the dead lanes hand in their ray ...
+            if (!alive && valid) {
+                if (p.trail) p.trail_hops[slot] = hops;
+                if (p.tile_cost) atomicMax(p.tile_cost + slot / (uint32_t)kBlock, n);
+                const float a = 1.0f - T;
+                if constexpr (HALF) {
+                    uint32_t lo = (uint32_t)float_to_half_bits(Cr) | ((uint32_t)float_to_half_bits(Cg) << 16);
+                    uint32_t hi = (uint32_t)float_to_half_bits(Cb) | ((uint32_t)float_to_half_bits(a) << 16);
+                    reinterpret_cast<uint2 *>(p.rgba)[ray] = make_uint2(lo, hi);
+                } else {
+                    reinterpret_cast<float4 *>(p.rgba)[ray] = make_float4(Cr, Cg, Cb, a);
+                }
+                if (p.nint) p.nint[ray] = n;
+                valid = false;
+            }
+            // ---- ... and take the next ones: one atomic for the wave, the ballot's prefix count ranks the lanes
+            const unsigned long long dead = ~live;
+            const uint32_t need = (uint32_t)__builtin_popcountll(dead);
+            uint32_t base = 0;
+            if (lane == 0u) base = atomicAdd(queue, need);
+            base = readlane(base, 0);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(dead & ((1ull << lane) - 1ull));
+            more = base + need < total;
+            if (!alive) {
+                const uint32_t q = base + rank;
+                slot = kNone;
+                if (q < total && map_slot(p.grid, q / (uint32_t)kBlock, q % (uint32_t)kBlock, queue_blocks, ray, slot)) {
+                    const float *rp = p.rays + (size_t)ray * 6;
+                    Ox = rp[0];
+                    Oy = rp[1];
+                    Oz = rp[2];
+                    dx = rp[3];
+                    dy = rp[4];
+                    dz = rp[5];
+                    const float nrm = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+                    dx = dx / nrm;
+                    dy = dy / nrm;
+                    dz = dz / nrm;
+                    cur = p.start[ray];
+                    sh_basis<DEG>(dx, dy, dz, sh);
+                    T = 1.0f;
+                    Cr = Cg = Cb = 0.0f;
+                    t0 = 0.0f;
+                    n = 0;
+                    hops = 0;
+                    nb = fv.poff[cur];
+                    cnt = fv.poff[cur + 1] - nb;
+                    head = fv.cells[cur];
+                    alive = valid = true;
+                } else if (slot != kNone && p.trail) {
+                    p.trail_hops[slot] = 0u;       // a slot of the launch without a ray (frame edge): nothing to replay
+                }
+            }
+            live = ballot(alive);
+        }
+        if (live == 0ull) {
+            if (!more) break;
+            continue;
+        }
+        // ---- one step of every live lane: forward_kernel's body
+        if (alive) {
+            n++;
+            if (n > max_steps) alive = false;
+        }
+        ScanResult sr;
+        sr.t1 = __builtin_inff();
+        sr.k = kNone;
+        if (alive) {
+            sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
+            if (sr.k == kNone) alive = false;
+        }
+        uint32_t nxt = 0, nnb = 0, ncnt = 0;
+        float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (alive) {
+            const Link link = fv.link[nb + sr.k];
+            nxt = link.nbr;
+            nnb = link.first;
+            ncnt = link.count;
+            nhead = fv.cells[nxt];
+            if (p.trail) {
+                if (hops < p.trail_cap) p.trail[(size_t)hops * p.trail_slots + slot] = nxt;
+                hops++;
+            }
+        }
+        if (alive) {
+            const float t1 = sr.t1;
+            if (t1 > t0 && head.w != 0.0f) {
+                const float sdens = head.w;
+                float r = 0.0f, g = 0.0f, b = 0.0f;
+                if (sdens > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
+                const float dt = __builtin_fmaxf(t1 - t0, 0.0f);
+                const float alpha = 1.0f - exp_(-sdens * dt);
+                const float w = T * alpha;
+                if (p.contribution) unsafeAtomicAdd(p.contribution + cur, w);
+                Cr = fma_(w, r, Cr);
+                Cg = fma_(w, g, Cg);
+                Cb = fma_(w, b, Cb);
+                T = T * (1.0f - alpha);
+                if (!(T > thr)) alive = false;
+            }
+            t0 = __builtin_fmaxf(t0, t1);
+            cur = nxt;
+            head = nhead;
+            nb = nnb;
+            cnt = ncnt;
+        }
+    }
+    // the rays that ended after the last refill
+    if (valid) {
+        if (p.trail) p.trail_hops[slot] = hops;
+        if (p.tile_cost) atomicMax(p.tile_cost + slot / (uint32_t)kBlock, n);
+        const float a = 1.0f - T;
+        if constexpr (HALF) {
+            uint32_t lo = (uint32_t)float_to_half_bits(Cr) | ((uint32_t)float_to_half_bits(Cg) << 16);
+            uint32_t hi = (uint32_t)float_to_half_bits(Cb) | ((uint32_t)float_to_half_bits(a) << 16);
+            reinterpret_cast<uint2 *>(p.rgba)[ray] = make_uint2(lo, hi);
+        } else {
+            reinterpret_cast<float4 *>(p.rgba)[ray] = make_float4(Cr, Cg, Cb, a);
+        }
+        if (p.nint) p.nint[ray] = n;
     }
 }
 
@@ -2302,7 +2473,13 @@ struct LaunchForward {
         // waves per SIMD (the launch is as long as its longest ray's chain of dependent loads).
         const bool eager = forward_mode ? forward_mode == 2u : (p.grid.img_w == 0 || nb <= kResidentBlocks);
         const dim3 g(nb), b(kBlock);
-        if (forward_mode == 3u) {   // the reference's quotient scan (scan_faces_strict); statistics stay on the canonical scan
+        if (forward_mode == 4u && !bench && !p.nq && !p.stats && p.queue) {
+            // persistent waves: as many blocks as are resident at once, refilled from the queue of the ordinary launch
+            const uint32_t resident = 256u * (uint32_t)(DEG <= 2 ? RF_PERSISTENT_WAVES : 4);
+            hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
+            hipLaunchKernelGGL((forward_persistent_kernel<DEG, HALF>), dim3(nb < resident ? nb : resident), b, 0, stream, p,
+                               p.queue, nb);
+        } else if (forward_mode == 3u) {   // the reference's quotient scan (scan_faces_strict); statistics stay on the canonical scan
             if (bench)
                 hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false, kScanStrict>), g, b, 0, stream, p);
             else if (p.nq)
@@ -2471,7 +2648,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_depths || !quantile_point_indices))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: depth quantile buffers missing");
-    if (opts->forward_mode > 3u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: forward_mode must be 0..3");
+    if (opts->forward_mode > 4u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: forward_mode must be 0..4");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -2500,6 +2677,8 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
     p.visit_marks = opts->stats ? opts->visit_marks : nullptr;
     p.tile_cost = opts->tile_cost;
+    // the scan scratch of the packing (per-chunk sums) is free once the foam is packed: its first word is the queue head
+    p.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(opts->workspace) + L.scan_off);
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: trail_slots smaller than rf_trail_slots()");
@@ -2533,7 +2712,7 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
         return fail(RF_ERR_INVALID_ARGUMENT, "depth_grad must be provided if depth_quantiles is provided");
     if (opts->backward_mode > 4u)
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0..4");
-    if (opts->forward_mode > 3u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: forward_mode must be 0..3");
+    if (opts->forward_mode > 4u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: forward_mode must be 0..4");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -2621,7 +2800,7 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
     p.cam = *camera;
     p.inv_tan_half_fov = 1.0f / tanf(camera->fov * 0.5f);
     p.rgba8 = ray_rgba;
-    if (opts->forward_mode > 3u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_benchmark: forward_mode must be 0..3");
+    if (opts->forward_mode > 4u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_benchmark: forward_mode must be 0..4");
     return dispatch<LaunchForward>(sh_degree, half, p, true, opts->forward_mode == 3u ? 3u : 1u, s);
 }
 

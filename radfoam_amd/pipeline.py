@@ -216,7 +216,8 @@ class Pipeline:
         #: 0 auto, 1 face blocks requested one at a time, 2 the first six of a cell together (rf_launch_opts.forward_mode;
         #: same results, auto picks by launch shape); 3 = the reference's own per-face quotient scan
         #: (tracing_utils.cuh:43-67) in trace_forward, trace_backward and trace_benchmark: the reference's tie-breaking
-        #: where two exits agree to an ulp, at the price of a divide per face (``strict_reference_scan`` sets it)
+        #: where two exits agree to an ulp, at the price of a divide per face (``strict_reference_scan`` sets it); 4 =
+        #: experiment: persistent waves refilling dead lanes from a queue (ballot + prefix count; slower)
         self.forward_mode = 0
         #: layout of the attr_grad accumulator: "auto" = rows on 64-byte lines at a pitch of 16 / 32 / 64 floats (fewer
         #: atomic line requests per gradient row; trace_backward then returns attr_grad as a [N, A] view of the padded

@@ -45,11 +45,12 @@ def _run_forward(pipe, fm, rays, start, attr_dtype=None, **kw):
     return {k: v.cpu() for k, v in out.items()}, (p, a, adj, off, r, s)
 
 
-@pytest.mark.parametrize("forward_mode", [1, 2])
+@pytest.mark.parametrize("forward_mode", [1, 2, 4])
 @pytest.mark.parametrize("d", [0, 1, 2, 3])
 def test_forward_image_bit_exact(foam_factory, d, forward_mode):
     """forward_mode: 1 = face blocks requested one at a time (what large image launches run), 2 = the first six of a
-    cell together (flat batches and small launches: what mode 0 picks for every other test of this file)."""
+    cell together (flat batches and small launches: what mode 0 picks for every other test of this file), 4 = persistent
+    waves that refill their dead lanes from a queue (experiment: ballot / prefix-sum compaction of live rays)."""
     fm = foam_factory(6000, d, 11)
     cam, rays, start = H.camera_setup(fm, 96, 64)
     ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
@@ -982,3 +983,34 @@ def test_gradient_row_pitch_does_not_change_the_gradients(foam_factory, d, image
     bad.gradient_row_pitch = A - 1
     with pytest.raises(RuntimeError, match="gradient_row_pitch"):
         bad.trace_backward(p, a, adj, off, t(rays), t(starts), t(fwd["rgba"]), t(g))
+
+
+@pytest.mark.parametrize("d,image", [(2, True), (3, False), (1, False)])
+def test_persistent_forward_feeds_the_replay(foam_factory, d, image):
+    """forward_mode 4 (persistent waves refilled from a queue by ballot + prefix count): rgba / num_intersections /
+    contribution as the oracle's, and the trail it records -- slots are those of the ordinary launch, whichever lane walked
+    the ray -- replayed by trace_backward (both backward paths) gives the oracle's gradients."""
+    fm, rays, starts, q, dg, g, err, fwd, ref = _backward_case(foam_factory, d, 80 + d, image, False, False,
+                                                               n_points=7000)
+    if not image:      # large enough for the sorted order (Pipeline.reorder_min_rays)
+        rays, starts = H.random_rays(fm, 20_000, seed=91)
+        rng = np.random.default_rng(5)
+        g = rng.normal(size=rays.shape[:-1] + (4,)).astype(np.float32)
+        args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+        fwd = O.trace_forward(*args, rays, starts, return_contribution=True)
+        ref = O.trace_backward(*args, rays, starts, fwd["rgba"], g, num_threads=1)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    t = lambda x: None if x is None else torch.from_numpy(x).to(DEV)
+    pipe = _pipeline(d)
+    pipe.forward_mode = 4
+    f = pipe.trace_forward(p, a, adj, off, t(rays), t(starts), return_contribution=not image)
+    np.testing.assert_array_equal(f["rgba"].cpu().numpy().view(np.uint32), fwd["rgba"].view(np.uint32))
+    np.testing.assert_array_equal(f["num_intersections"].cpu().numpy().view(np.uint32), fwd["num_intersections"])
+    if not image:
+        np.testing.assert_allclose(f["contribution"].cpu().numpy(), fwd["contribution"], rtol=1e-4, atol=1e-6)
+    assert pipe._trail is not None
+    out = pipe.trace_backward(p, a, adj, off, t(rays), t(starts), f["rgba"], t(g))
+    torch.cuda.synchronize()
+    for key in ("points_grad", "attr_grad"):
+        ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
+        assert ok and rel < 1e-5, (key, rel, worst)
