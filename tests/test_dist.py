@@ -188,3 +188,28 @@ def test_balanced_row_blocks():
     spike[3] = 1.0
     b = rdist.balanced_row_blocks(spike, 4, align=8)
     assert b[0] == 0 and b[-1] == 64 and all(x < y for x, y in zip(b, b[1:]))
+
+
+def test_sparse_exchange_insists_on_dense_gradient_rows():
+    """Round 4: Pipeline.trace_backward accumulates attr_grad in rows padded to 64-byte lines by default and returns a
+    [N, A] view of them; the exchange kernels (rf_compact_grad_rows / rf_scatter_grad_rows) read and write the reference's
+    dense rows, so ShardedTracer switches its pipeline to gradient_row_pitch = "dense" when it exchanges sparsely, and the
+    exchange refuses a strided attr_grad instead of reading the wrong floats."""
+    import torch
+
+    from radfoam_amd import dist as rdist
+
+    class _Pipe:
+        gradient_row_pitch = "auto"
+
+    pipe = _Pipe()
+    rdist.ShardedTracer(pipe, exchange="dense")
+    assert pipe.gradient_row_pitch == "auto"
+    rdist.ShardedTracer(pipe, exchange="sparse")
+    assert pipe.gradient_row_pitch == "dense"
+    ex = rdist.SparseGradExchange()
+    n, a = 10, 13
+    padded = torch.zeros(n, 16)[:, :a]
+    send = torch.zeros(n, ex._pitch(a))
+    with pytest.raises(RuntimeError, match="dense"):
+        ex._compact(torch.zeros(n, 3), padded, send, torch.zeros(1, dtype=torch.int32))
