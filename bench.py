@@ -138,7 +138,8 @@ def parse_args(argv=None):
                          "rf_launch_opts.forward_mode 3) in forward, backward and render; the CPU baseline then runs the "
                          "oracle in its 'reference' scan mode, so that the bitwise comparison still holds")
     ap.add_argument("--forward-mode", type=int, default=None,
-                    help="Pipeline.forward_mode (experiments): 1 blocks, 2 eager, 3 = --strict-scan, 4 persistent waves with refill")
+                    help="Pipeline.forward_mode (experiments): 1 blocks, 2 eager, 3 = --strict-scan, 4 persistent waves with refill, "
+                         "5 eager behind the block-level LDS cell table (auto for sorted flat batches)")
     ap.add_argument("--grad-pitch", default=None, help="Pipeline.gradient_row_pitch: auto (default), dense, or floats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true",

@@ -100,7 +100,9 @@ typedef struct rf_launch_opts {
                               /*   face).  rf_trace_backward and rf_trace_benchmark honour 3 as well (the replay of a     */
                               /*   trail must be given the mode its forward ran in); they ignore 0..2.                    */
                               /*   4 (rf_trace_forward, experiment) = persistent waves that refill their dead lanes from  */
-                              /*   a queue by ballot + prefix count -- same results, slower on every workload measured    */
+                              /*   a queue by ballot + prefix count -- same results, slower on every workload measured;   */
+                              /*   5 = mode 2 behind a block-level LDS table of cell records + face blocks (what auto     */
+                              /*   picks for a flat batch given with a ray_order: its 256-slot groups re-visit cells).    */
     /* Optional: device uint32[rf_launch_blocks(...)], the tile each block of the launch walks -- a 16x16-pixel tile of   */
     /* an image-shaped batch, a group of 256 consecutive thread slots of a flat one (values >= the number of tiles: the   */
     /* block owns no rays).  It MUST name every tile exactly once; the library does not check it (the table lives on the */

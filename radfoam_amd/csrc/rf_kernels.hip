@@ -381,6 +381,78 @@ __device__ __forceinline__ ScanResult scan_faces_eager(const GeoBlocks<K> &G, co
     return r;
 }
 
+// ---- block-level LDS cache of cell entries (rf_launch_opts.forward_mode = 5; experiment) -----------------------------
+// The rays of a 256-slot group of a sorted flat batch meet a cell about eleven times, tens of steps apart
+// (scripts/model_train_batch.py): too far for L1, and 160 resident blocks per XCD leave each an L2 share of ~100 cells.
+// A direct-mapped table in LDS keyed by cell -- {cell record, the first kEagerBlocks face blocks}, 176 bytes -- serves
+// what a block re-visits (the model: 0.56 -> 0.25 fetches per visit at 304 entries), and a hit takes the second
+// dependent round trip (link -> cell record + face blocks) out of the hop.  No lock, no barrier in the walk: an entry
+// carries a 64-bit tag {version, cell}; a writer claims it by compare-and-swap to {version + 1, busy}, writes, and
+// publishes {version + 1, cell}; a reader takes tag, data, tag again in program order (a wave's LDS operations execute in
+// order) and has a hit only when both tags are the same and name its cell.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t kCacheBusy = 0xFFFFFFFEu;
+
+template <int K>
+struct __attribute__((aligned(16))) CellEntry {
+    unsigned long long tag;
+    unsigned long long unused;
+    u32x4 head;        // {x, y, z, density}
+    u32x4 A[K];        // GeoXY of the first K face blocks
+    u32x2 B[K];        // GeoZ
+};
+
+__device__ __forceinline__ uint32_t cache_slot(uint32_t cell, uint32_t entries) {
+    return __umulhi(cell * 2654435761u, entries);
+}
+
+// true: head / G now hold the entry of `cell`
+template <int K>
+__device__ __forceinline__ bool cache_read(CellEntry<K> *cache, uint32_t entries, uint32_t cell, float4 &head,
+                                           GeoBlocks<K> &G) {
+    // (explicitly LDS-typed: the optimiser does not infer the address space of volatile accesses, and flat loads count
+    // against both wait counters)
+    typedef volatile __attribute__((address_space(3))) CellEntry<K> *EntryPtr;
+    EntryPtr e = (EntryPtr)(cache + cache_slot(cell, entries));
+    const unsigned long long t0 = e->tag;
+    const u32x4 h = e->head;
+    u32x4 a[K];
+    u32x2 b[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) a[i] = e->A[i];
+#pragma unroll
+    for (int i = 0; i < K; ++i) b[i] = e->B[i];
+    const unsigned long long t1 = e->tag;
+    if ((uint32_t)t0 != cell || t1 != t0) return false;
+    head = __builtin_bit_cast(float4, h);
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        G.A[i] = __builtin_bit_cast(GeoXY, a[i]);
+        G.B[i] = __builtin_bit_cast(GeoZ, b[i]);
+    }
+    return true;
+}
+
+template <int K>
+__device__ __forceinline__ void cache_fill(CellEntry<K> *cache, uint32_t entries, uint32_t cell, const float4 &head,
+                                           const GeoBlocks<K> &G) {
+    CellEntry<K> *e = cache + cache_slot(cell, entries);
+    typedef volatile __attribute__((address_space(3))) CellEntry<K> *EntryPtr;
+    EntryPtr v = (EntryPtr)e;
+    const unsigned long long old = v->tag;
+    const uint32_t holds = (uint32_t)old;
+    if (holds == cell || holds == kCacheBusy) return;     // already there / another lane is writing it
+    const unsigned long long version = ((old >> 32) + 1ull) << 32;
+    if (atomicCAS(&e->tag, old, version | (unsigned long long)kCacheBusy) != old) return;
+    v->head = __builtin_bit_cast(u32x4, head);
+#pragma unroll
+    for (int i = 0; i < K; ++i) v->A[i] = __builtin_bit_cast(u32x4, G.A[i]);
+#pragma unroll
+    for (int i = 0; i < K; ++i) v->B[i] = __builtin_bit_cast(u32x2, G.B[i]);
+    v->tag = version | (unsigned long long)cell;
+}
+
 // The reference's own evaluation of a scan (tracing_utils.cuh:43-67), selectable as rf_launch_opts.forward_mode = 3:
 // v = (P + o/2) - O, EVERY face divided (IEEE), a running minimum of the rounded quotients, strict '<' (the first
 // minimum wins).  Same face table, same dot-product association as everywhere else; bit-identical to the CPU checker's
@@ -577,17 +649,34 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b, float 
 #ifndef RF_FWD_WAVES_EAGER
 #define RF_FWD_WAVES_EAGER 4
 #endif
-constexpr int kScanBlocks = 0, kScanEager = 1, kScanStrict = 2;   // forward_kernel's SCAN parameter
+constexpr int kScanBlocks = 0, kScanEager = 1, kScanStrict = 2, kScanCached = 3;   // forward_kernel's SCAN parameter
 constexpr int forward_waves(int deg, bool half, bool quant, bool stats, int scan) {
-    if (scan == kScanEager) return (deg <= 2 && !quant) ? RF_FWD_WAVES_EAGER : 3;
+    if (scan == kScanEager || scan == kScanCached) return (deg <= 2 && !quant) ? RF_FWD_WAVES_EAGER : 3;
     if (quant || stats) return RF_FWD_WAVES_OTHER;
     return deg <= 2 ? RF_FWD_WAVES_MAIN : (half ? RF_FWD_WAVES_D3_HALF : RF_FWD_WAVES_D3);
 }
 
+// entries of the kScanCached instances' LDS table: what the blocks that share a CU leave each other of its 160 KB
+#ifndef RF_CELL_CACHE_ENTRIES
+#define RF_CELL_CACHE_ENTRIES 0
+#endif
+constexpr uint32_t cell_cache_entries(int waves) {
+    return RF_CELL_CACHE_ENTRIES ? (uint32_t)RF_CELL_CACHE_ENTRIES : (waves <= 3 ? 304u : 232u);
+}
+
 template <int DEG, bool HALF, bool BENCH, bool QUANT, bool STATS, int SCAN>
 __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN)) void forward_kernel(FwdParams p) {
-    constexpr bool EAGER = SCAN == kScanEager;
+    constexpr bool CACHED = SCAN == kScanCached;
+    constexpr bool EAGER = SCAN == kScanEager || CACHED;
     const uint32_t lane = threadIdx.x & 63u;
+    constexpr uint32_t kEntries = cell_cache_entries(forward_waves(DEG, HALF, QUANT, STATS, SCAN));
+    CellEntry<kEagerBlocks> *cache = nullptr;
+    if constexpr (CACHED) {
+        __shared__ CellEntry<kEagerBlocks> s_cells[kEntries];
+        for (uint32_t e = threadIdx.x; e < kEntries; e += (uint32_t)kBlock) s_cells[e].tag = (unsigned long long)kNone;
+        __syncthreads();    // the only barrier of the launch: before the walk
+        cache = s_cells;
+    }
 #ifdef RF_EXPERIMENT_TIMELINE
     const unsigned long long tl_start = wall_clock64();
 #endif
@@ -655,6 +744,7 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
     }
     GeoBlocks<EAGER ? kEagerBlocks : 0> GB;
     if constexpr (EAGER) load_geo_blocks(fv.geo, nb, cnt, GB);
+    bool fetched = alive;   // CACHED: head / GB of the current cell came from memory, the table may want them
     uint32_t wave_steps = 0;
     uint32_t hops = 0;
     while (ballot(alive) != 0ull) {
@@ -666,6 +756,7 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
         ScanResult sr;
         sr.t1 = __builtin_inff();
         sr.k = kNone;
+        const bool scanned = alive;
         if (alive) {
             if constexpr (EAGER)
                 sr = scan_faces_eager(GB, fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, Ox, Oy, Oz, dx, dy, dz);
@@ -682,13 +773,34 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
         float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if constexpr (CACHED) {
+            // everything requested so far has been consumed by the scan (or belongs to lanes that are done): telling the
+            // compiler so keeps its wait for the table's stores below from covering the link load as well
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            Link link{0u, 0u, 0u};
+            if (alive) link = fv.link[nb + sr.k];
+            // while the link is on its way: what this cell's scan fetched from memory goes into the table
+            if (scanned && fetched) cache_fill(cache, kEntries, cur, head, GB);
+            if (alive) {
+                nxt = link.nbr;
+                nnb = link.first;
+                ncnt = link.count;
+                fetched = !cache_read(cache, kEntries, nxt, nhead, GB);
+                if (fetched) {
+                    nhead = fv.cells[nxt];
+                    load_geo_blocks(fv.geo, nnb, ncnt, GB);
+                }
+            }
+        }
         if (alive) {
-            const Link link = fv.link[nb + sr.k];
-            nxt = link.nbr;
-            nnb = link.first;
-            ncnt = link.count;
-            nhead = fv.cells[nxt];
-            if constexpr (EAGER) load_geo_blocks(fv.geo, nnb, ncnt, GB);
+            if constexpr (!CACHED) {
+                const Link link = fv.link[nb + sr.k];
+                nxt = link.nbr;
+                nnb = link.first;
+                ncnt = link.count;
+                nhead = fv.cells[nxt];
+                if constexpr (EAGER) load_geo_blocks(fv.geo, nnb, ncnt, GB);
+            }
             if constexpr (!BENCH) {
                 // trail: the cell each hop enters, for trace_backward to replay
                 if (p.trail) {
@@ -2472,6 +2584,11 @@ struct LaunchForward {
         // little, most face lists come from HBM) and any launch small enough to be resident at once with at most four
         // waves per SIMD (the launch is as long as its longest ray's chain of dependent loads).
         const bool eager = forward_mode ? forward_mode == 2u : (p.grid.img_w == 0 || nb <= kResidentBlocks);
+        // ... behind a block-level LDS table of cell records and face blocks where a block's rays come back to the cells
+        // they crossed: the 256-slot groups of a SORTED flat batch (rf_build_ray_order).  Training batch of bench.py
+        // (profiles/r04/n_cell_table_ab.log): forward 4.36 -> 3.85 ms at SH 3, 4.29 -> 3.56 at SH 2, 6.36 -> 5.40 with every
+        // segment lit; whole batch bitwise equal to the CPU checker.
+        const bool cached = forward_mode ? forward_mode == 5u : (p.grid.img_w == 0 && p.grid.order != nullptr);
         const dim3 g(nb), b(kBlock);
         if (forward_mode == 4u && !bench && !p.nq && !p.stats && p.queue) {
             // persistent waves: as many blocks as are resident at once, refilled from the queue of the ordinary launch
@@ -2486,6 +2603,11 @@ struct LaunchForward {
                 hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, kScanStrict>), g, b, 0, stream, p);
             else
                 hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, kScanStrict>), g, b, 0, stream, p);
+        } else if (cached && !bench && !p.stats) {
+            if (p.nq)
+                hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, true, false, kScanCached>), g, b, 0, stream, p);
+            else
+                hipLaunchKernelGGL((forward_kernel<DEG, HALF, false, false, false, kScanCached>), g, b, 0, stream, p);
         } else if (bench)
             hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false, kScanBlocks>), g, b, 0, stream, p);
         else if (p.stats)
@@ -2648,7 +2770,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: null pointer");
     if (num_depth_quantiles && depth_quantiles && (!quantile_depths || !quantile_point_indices))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: depth quantile buffers missing");
-    if (opts->forward_mode > 4u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: forward_mode must be 0..4");
+    if (opts->forward_mode > 5u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: forward_mode must be 0..5");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -2712,7 +2834,7 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
         return fail(RF_ERR_INVALID_ARGUMENT, "depth_grad must be provided if depth_quantiles is provided");
     if (opts->backward_mode > 4u)
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: backward_mode must be 0..4");
-    if (opts->forward_mode > 4u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: forward_mode must be 0..4");
+    if (opts->forward_mode > 5u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: forward_mode must be 0..5");
     const bool half = attr_type == RF_ATTR_FLOAT16;
     hipStream_t s = static_cast<hipStream_t>(stream);
     FoamLayout L = foam_layout(num_points, point_adjacency_size, sh_degree, half);
@@ -2800,7 +2922,7 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
     p.cam = *camera;
     p.inv_tan_half_fov = 1.0f / tanf(camera->fov * 0.5f);
     p.rgba8 = ray_rgba;
-    if (opts->forward_mode > 4u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_benchmark: forward_mode must be 0..4");
+    if (opts->forward_mode > 5u) return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_benchmark: forward_mode must be 0..5");
     return dispatch<LaunchForward>(sh_degree, half, p, true, opts->forward_mode == 3u ? 3u : 1u, s);
 }
 

@@ -163,7 +163,8 @@ def tile_order(cost, default, rule):
       "tail[:count]"  the static order, except that the `count` (2048) cheapest tiles of the frame come last, the longest
                       of them first: what is still running when the launch drains is short, and the bulk of the launch
                       keeps the strips of the static dealing;
-      "global"        all tiles longest first, whatever the XCD.
+      "global"        all tiles longest first, whatever the XCD;
+      "chunk:n"       runs of n consecutive tiles per XCD, in tile order (experiment: L2 sharing of flat batches).
     Returns int64 [len(default)]: a permutation of `default`."""
     nt = int(cost.numel())
     if rule == "global":
@@ -189,6 +190,17 @@ def tile_order(cost, default, rule):
         key = torch.where(cheap, big + (int(2 ** 24) - c.to(torch.int64)), pos)
         key = torch.where(c < 0, torch.full_like(key, big + int(2 ** 25)), key)
         idx = torch.sort(key, dim=0, stable=True).indices
+    elif rule.startswith("chunk:"):
+        # every XCD takes runs of <n> consecutive tiles (flat batches: 256-slot groups of the sorted order, i.e. one
+        # compact patch of directions of one camera per run): what is resident on an XCD at a time shares its L2
+        n = max(1, int(rule.split(":")[1]))
+        rows = int(per_xcd.shape[0])
+        pos = torch.arange(rows, device=default.device, dtype=torch.int64).view(-1, 1)
+        x = torch.arange(8, device=default.device, dtype=torch.int64).view(1, -1)
+        rnd = torch.div(pos, n, rounding_mode="floor")
+        width = torch.clamp(rows - rnd * n, max=n)                   # the last round of an XCD may be shorter
+        tiles = rnd * (8 * n) + x * width + (pos - rnd * n)
+        return torch.where(tiles < nt, tiles, torch.full_like(tiles, nt)).reshape(-1)
     else:
         raise ValueError(f"unknown tile order rule {rule!r}")
     return torch.gather(per_xcd, 0, idx).reshape(-1)
@@ -217,7 +229,8 @@ class Pipeline:
         #: same results, auto picks by launch shape); 3 = the reference's own per-face quotient scan
         #: (tracing_utils.cuh:43-67) in trace_forward, trace_backward and trace_benchmark: the reference's tie-breaking
         #: where two exits agree to an ulp, at the price of a divide per face (``strict_reference_scan`` sets it); 4 =
-        #: experiment: persistent waves refilling dead lanes from a queue (ballot + prefix count; slower)
+        #: experiment: persistent waves refilling dead lanes from a queue (ballot + prefix count; slower);
+        #: 5 = mode 2 behind a block-level LDS table of cell records and face blocks (auto picks it for sorted flat batches)
         self.forward_mode = 0
         #: layout of the attr_grad accumulator: "auto" = rows on 64-byte lines at a pitch of 16 / 32 / 64 floats (fewer
         #: atomic line requests per gradient row; trace_backward then returns attr_grad as a [N, A] view of the padded

@@ -8,6 +8,7 @@ foam) maps onto waves: per-ray cell sequences from the oracle (rfo_trace_paths),
   wave_distinct       sum over wave-steps of the distinct cells the wave's active lanes sit in = fetches when only lanes
                       that hit the same cell in the same instruction share (what the hardware coalesces)
   block_lru[K]        misses of a K-entry LRU of cell ids per block = fetches with a block-level software cache in LDS
+  block_direct[S]     the same for a direct-mapped table of S entries (what an LDS table without bookkeeping can be)
 
   python scripts/model_train_batch.py [--blocks 120] [--points 2000000] [--rays 1000000]
 """
@@ -147,6 +148,9 @@ def simulate_row_cache(cells, n, lit):
     return out
 
 
+DIRECT_SIZES = (128, 256, 384, 512, 768, 1024)
+
+
 def simulate_block(cells, t1, n, policy, delta, lru_sizes):
     """cells/t1: [256, cap]; n: [256] scans per ray.  Lockstep per wave of 64 lanes; the four waves of a block advance
     round-robin one wave-step at a time (the LRU sees their interleaved fetches)."""
@@ -158,6 +162,8 @@ def simulate_block(cells, t1, n, policy, delta, lru_sizes):
     wave_distinct = 0
     lrus = {k: collections.OrderedDict() for k in lru_sizes}
     miss = {k: 0 for k in lru_sizes}
+    dms = {k: np.full(k, -1, dtype=np.int64) for k in DIRECT_SIZES}     # direct-mapped: what an LDS table can be
+    dmiss = {k: 0 for k in DIRECT_SIZES}
     alive = pos < n
     while alive.any():
         for w, lanes in enumerate(waves):
@@ -184,12 +190,19 @@ def simulate_block(cells, t1, n, policy, delta, lru_sizes):
                         l[c] = True
                         if len(l) > k:
                             l.popitem(last=False)
+            for k in DIRECT_SIZES:
+                t = dms[k]
+                h = (uniq.astype(np.int64) * 2654435761 % (1 << 32)) * k >> 32
+                for c, sl in zip(uniq.tolist(), h.tolist()):
+                    if t[sl] != c:
+                        dmiss[k] += 1
+                        t[sl] = c
             tt = t1[idx, pos[idx]]
             t0[idx] = np.maximum(t0[idx], np.where(np.isfinite(tt), tt, t0[idx]))
             pos[idx] += 1
         alive = pos < n
     return dict(wave_steps=sum(steps), lane_visits=lane_visits, wave_distinct=wave_distinct,
-                **{f"block_lru{k}": miss[k] for k in lru_sizes})
+                **{f"block_lru{k}": miss[k] for k in lru_sizes}, **{f"block_direct{k}": dmiss[k] for k in DIRECT_SIZES})
 
 
 def main():
@@ -249,6 +262,8 @@ def main():
         rec["fetches_per_visit_wave_coalesced"] = round(rec["wave_distinct"] / rec["lane_visits"], 3)
         for k in lru_sizes:
             rec[f"fetches_per_visit_block_lru{k}"] = round(rec[f"block_lru{k}"] / rec["lane_visits"], 3)
+        for k in DIRECT_SIZES:
+            rec[f"fetches_per_visit_block_direct{k}"] = round(rec[f"block_direct{k}"] / rec["lane_visits"], 3)
         result[name] = rec
         print(name, json.dumps(rec))
     wb = collections.Counter()

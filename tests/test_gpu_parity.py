@@ -45,12 +45,13 @@ def _run_forward(pipe, fm, rays, start, attr_dtype=None, **kw):
     return {k: v.cpu() for k, v in out.items()}, (p, a, adj, off, r, s)
 
 
-@pytest.mark.parametrize("forward_mode", [1, 2, 4])
+@pytest.mark.parametrize("forward_mode", [1, 2, 4, 5])
 @pytest.mark.parametrize("d", [0, 1, 2, 3])
 def test_forward_image_bit_exact(foam_factory, d, forward_mode):
     """forward_mode: 1 = face blocks requested one at a time (what large image launches run), 2 = the first six of a
     cell together (flat batches and small launches: what mode 0 picks for every other test of this file), 4 = persistent
-    waves that refill their dead lanes from a queue (experiment: ballot / prefix-sum compaction of live rays)."""
+    waves that refill their dead lanes from a queue (experiment: ballot / prefix-sum compaction of live rays), 5 = the
+    eager instance behind a block-level LDS table of cell records and face blocks (experiment)."""
     fm = foam_factory(6000, d, 11)
     cam, rays, start = H.camera_setup(fm, 96, 64)
     ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"],
@@ -64,7 +65,7 @@ def test_forward_image_bit_exact(foam_factory, d, forward_mode):
     assert ref["rgba"][..., 3].max() > 0.5  # the scene is actually hit
 
 
-@pytest.mark.parametrize("forward_mode", [1, 2])
+@pytest.mark.parametrize("forward_mode", [1, 2, 5])
 @pytest.mark.parametrize("d", [0, 2, 3])
 def test_forward_flat_rays_quantiles_contribution(foam_factory, d, forward_mode):
     fm = foam_factory(6000, d, 12)
@@ -88,7 +89,7 @@ def test_forward_flat_rays_quantiles_contribution(foam_factory, d, forward_mode)
     assert abs(float(got["contribution"].double().sum()) - float(got["rgba"][..., 3].double().sum())) < 1e-2
 
 
-@pytest.mark.parametrize("forward_mode", [1, 2])
+@pytest.mark.parametrize("forward_mode", [1, 2, 5])
 @pytest.mark.parametrize("d", [0, 1, 2, 3])
 def test_forward_half_attributes(foam_factory, d, forward_mode):
     fm = foam_factory(6000, d, 13)
@@ -985,11 +986,14 @@ def test_gradient_row_pitch_does_not_change_the_gradients(foam_factory, d, image
         bad.trace_backward(p, a, adj, off, t(rays), t(starts), t(fwd["rgba"]), t(g))
 
 
+@pytest.mark.parametrize("forward_mode", [4, 5])
 @pytest.mark.parametrize("d,image", [(2, True), (3, False), (1, False)])
-def test_persistent_forward_feeds_the_replay(foam_factory, d, image):
+def test_persistent_forward_feeds_the_replay(foam_factory, d, image, forward_mode):
     """forward_mode 4 (persistent waves refilled from a queue by ballot + prefix count): rgba / num_intersections /
     contribution as the oracle's, and the trail it records -- slots are those of the ordinary launch, whichever lane walked
-    the ray -- replayed by trace_backward (both backward paths) gives the oracle's gradients."""
+    the ray -- replayed by trace_backward (both backward paths) gives the oracle's gradients.  forward_mode 5 (cell
+    records and face blocks served from a block-level LDS table, filled and read without locks by the block's four
+    waves): the same, on a sorted batch whose 256-slot groups do re-visit cells."""
     fm, rays, starts, q, dg, g, err, fwd, ref = _backward_case(foam_factory, d, 80 + d, image, False, False,
                                                                n_points=7000)
     if not image:      # large enough for the sorted order (Pipeline.reorder_min_rays)
@@ -1002,7 +1006,7 @@ def test_persistent_forward_feeds_the_replay(foam_factory, d, image):
     p, a, adj, off = H.to_torch_foam(fm, DEV)
     t = lambda x: None if x is None else torch.from_numpy(x).to(DEV)
     pipe = _pipeline(d)
-    pipe.forward_mode = 4
+    pipe.forward_mode = forward_mode
     f = pipe.trace_forward(p, a, adj, off, t(rays), t(starts), return_contribution=not image)
     np.testing.assert_array_equal(f["rgba"].cpu().numpy().view(np.uint32), fwd["rgba"].view(np.uint32))
     np.testing.assert_array_equal(f["num_intersections"].cpu().numpy().view(np.uint32), fwd["num_intersections"])
