@@ -1,5 +1,5 @@
 # the batch of one gpurun call (rewritten per call; what each call ran is recorded in profiles/README.md)
-# this call: block-level colour-row cache of the flat-batch replay (R rows, T table entries; rcC = occupancy control)
+# this call: SH-2 training batch, step counts and forward modes (the evidence run's 5.31 ms forward)
 R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p gpurun_out/cc
@@ -18,10 +18,24 @@ except Exception as e:
 PY
 }
 B=$R/radfoam_amd/libradfoam_hip.so
-for v in base rcA rcB rcC rcD rcE rcG; do
-  L=$R/radfoam_amd/libradfoam_hip_$v.so; [ $v = base ] && L=$B
-  run tb_$v $L --workload train-batch --no-cpu-baseline
-  run lit_$v $L --workload train-batch --no-cpu-baseline --empty-density 4.5e-6
-done
-run tb_rcA_cpu $R/radfoam_amd/libradfoam_hip_rcA.so --workload train-batch --empty-density 4.5e-6
-run tb_rcB_cpu $R/radfoam_amd/libradfoam_hip_rcB.so --workload train-batch --empty-density 4.5e-6
+run2() {  # name steps warmup args...
+  local name=$1 st=$2 wu=$3; shift 3
+  timeout 300 python bench.py --steps $st --warmup $wu --no-other-workloads --no-cpu-baseline "$@" 2>gpurun_out/cc/$name.err | tail -1 > gpurun_out/cc/$name.json
+  python - "$name" gpurun_out/cc/$name.json <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2])); det = d["detail"]
+    print(sys.argv[1], "Mrays/s", d["value"], "fwd", det.get("forward_ms"), "bwd", det.get("backward_ms"))
+except Exception as e:
+    print(sys.argv[1], "failed", e, open(sys.argv[2]).read()[-300:])
+PY
+}
+run2 sh2_auto_6   6 2  --workload train-batch --sh-degree 2
+run2 sh2_auto_10  10 3 --workload train-batch --sh-degree 2
+run2 sh2_m5_10    10 3 --workload train-batch --sh-degree 2 --forward-mode 5
+run2 sh2_m2_10    10 3 --workload train-batch --sh-degree 2 --forward-mode 2
+run2 sh2_auto_20  20 3 --workload train-batch --sh-degree 2
+run2 sh2_auto_10b 10 3 --workload train-batch --sh-degree 2
+run2 sh3_auto_20  20 3 --workload train-batch
+run2 sh1_auto_10  10 3 --workload train-batch --sh-degree 1
+run2 sh1_m2_10    10 3 --workload train-batch --sh-degree 1 --forward-mode 2
