@@ -99,6 +99,18 @@ def _tensor_key(t):
     return (t.data_ptr(), ver, tuple(t.shape), t.dtype, t.device, _EPOCH[0])
 
 
+def _source_key(t, t_c):
+    """Key of a per-ray input as the CALLER holds it.  ``t_c = t.contiguous()`` is a fresh copy whenever ``t`` is a strided
+    view (RadFoamScene.collect_error_map traces ``rays[:, d0::2, d1::2]``): keyed on the copy, the trace_backward that
+    follows -- autograd hands it the same view, which is copied again -- would find neither the ray order nor the hop trail
+    of its forward and re-walk every ray (70 ms instead of 8 for a 960x540 view of the 2 M-point scene).  So a view is keyed
+    on its own storage address, version, shape AND strides."""
+    if t is None or t_c is t:
+        return _tensor_key(t_c)
+    k = _tensor_key(t)
+    return k if isinstance(k, _Uncacheable) else k + (tuple(t.stride()), int(t.storage_offset()))
+
+
 def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -232,6 +244,8 @@ class Pipeline:
         #: experiment: persistent waves refilling dead lanes from a queue (ballot + prefix count; slower);
         #: 5 = mode 2 behind a block-level LDS table of cell records and face blocks (auto picks it for sorted flat batches)
         self.forward_mode = 0
+        #: set by trace_backward: True when it replayed the hop trail of its trace_forward, False when it walked again
+        self.last_backward_replayed = None
         #: layout of the attr_grad accumulator: "auto" = rows on 64-byte lines at a pitch of 16 / 32 / 64 floats (fewer
         #: atomic line requests per gradient row; trace_backward then returns attr_grad as a [N, A] view of the padded
         #: rows), "dense" = the reference's contiguous [N, A] (radfoam_amd.dist's sparse exchange needs it), or an int
@@ -505,16 +519,19 @@ class Pipeline:
     def _tkey(t):
         return _tensor_key(t)
 
-    def _trail_key(self, foam, rays, start, quantiles, settings):
-        return (tuple(self._tkey(t) for t in foam), self._tkey(rays), self._tkey(start), self._tkey(quantiles),
-                float(settings.weight_threshold), int(settings.max_intersections), int(self.forward_mode) == 3)
+    def _trail_key(self, foam, ray_keys, settings):
+        """``ray_keys``: _source_key of rays, start_point and depth_quantiles."""
+        return (tuple(self._tkey(t) for t in foam),) + tuple(ray_keys) + (
+            float(settings.weight_threshold), int(settings.max_intersections), int(self.forward_mode) == 3)
 
-    def _ray_order(self, opts, rays_c, start_c, num_rays):
+    def _ray_order(self, opts, rays_c, start_c, num_rays, key=None):
         """Set opts.ray_order for a flat batch: the permutation rf_build_ray_order computes, cached on
-        the identity + version of (rays, start_point) so that trace_backward reuses trace_forward's."""
+        the identity + version of (rays, start_point) so that trace_backward reuses trace_forward's.  ``key``: the
+        callers' (_source_key(rays), _source_key(start_point)) when the contiguous copies are not what they hold."""
         if not self.reorder_rays or opts.image_width or num_rays < self.reorder_min_rays:
             return
-        key = (self._tkey(rays_c), self._tkey(start_c))
+        if key is None:
+            key = (self._tkey(rays_c), self._tkey(start_c))
         cached = self._order
         if cached is None or cached["key"] != key:
             dev = rays_c.device
@@ -644,17 +661,17 @@ class Pipeline:
             return out
 
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape)
-        self._ray_order(opts, rays_c, start_c, num_rays)
+        ray_keys = (_source_key(rays, rays_c), _source_key(start_point, start_c), _source_key(depth_quantiles, quantiles_c))
+        self._ray_order(opts, rays_c, start_c, num_rays, key=ray_keys[:2])
         trail = None
         if self._wants_trail(points, attributes):
             trail = self._new_trail(opts, num_rays, dev)
         tiles_pending = None
         if opts.image_width:
-            tiles_pending = self._tile_cost_begin(opts, opts.image_height, opts.image_width,
-                                                  (self._tkey(rays_c), self._tkey(start_c)), dev,
+            tiles_pending = self._tile_cost_begin(opts, opts.image_height, opts.image_width, ray_keys[:2], dev,
                                                   backward_follows=trail is not None)
         elif opts.ray_order:
-            tiles_pending = self._tile_cost_begin(opts, "flat", num_rays, (self._tkey(rays_c), self._tkey(start_c)), dev)
+            tiles_pending = self._tile_cost_begin(opts, "flat", num_rays, ray_keys[:2], dev)
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_forward(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),
@@ -668,8 +685,9 @@ class Pipeline:
             self._probe_hops(trail[1])
             foam = (points_c, attributes_c, adjacency_c, offsets_c)
             self._trail = {
-                "key": self._trail_key(foam, rays_c, start_c, quantiles_c, settings),
-                "refs": foam + (rays_c, start_c, quantiles_c),   # keep the storages from being recycled
+                "key": self._trail_key(foam, ray_keys, settings),
+                # keep the keyed storages from being recycled (the caller's views as well as their contiguous copies)
+                "refs": foam + (rays_c, start_c, quantiles_c, rays, start_point, depth_quantiles),
                 "trail": trail[0], "hops": trail[1], "cap": opts.trail_cap, "slots": opts.trail_slots,
                 "order": opts.ray_order,   # the slot -> ray mapping the trail was recorded under
             }
@@ -858,11 +876,13 @@ class Pipeline:
             return out
 
         opts = self._launch_opts(points_c, attributes_c, adjacency_c, offsets_c, rays_c.shape, launch="backward")
-        self._ray_order(opts, rays_c, start_c, num_rays)
+        ray_keys = (_source_key(rays, rays_c), _source_key(start_point, start_c), _source_key(depth_quantiles, quantiles_c))
+        self._ray_order(opts, rays_c, start_c, num_rays, key=ray_keys[:2])
         tr = self._trail
+        self.last_backward_replayed = False
         if tr is not None and tr["order"] == opts.ray_order and \
-                tr["key"] == self._trail_key((points_c, attributes_c, adjacency_c, offsets_c),
-                                             rays_c, start_c, quantiles_c, settings):
+                tr["key"] == self._trail_key((points_c, attributes_c, adjacency_c, offsets_c), ray_keys, settings):
+            self.last_backward_replayed = True
             opts.trail = tr["trail"].data_ptr()
             opts.trail_hops = tr["hops"].data_ptr()
             opts.trail_cap = tr["cap"]

@@ -1018,3 +1018,34 @@ def test_persistent_forward_feeds_the_replay(foam_factory, d, image, forward_mod
     for key in ("points_grad", "attr_grad"):
         ok, rel, worst = H.grad_close(out[key].cpu().numpy(), ref[key])
         assert ok and rel < 1e-5, (key, rel, worst)
+
+
+def test_backward_of_a_strided_ray_view_replays_the_trail(foam_factory):
+    """collect_error_map (scene.py:518-537) traces a strided view of a frame's rays through TraceRays with a ray_error box:
+    forward and backward each copy the view, and the backward must still find the ray order and the hop trail of its
+    forward (keys on the caller's view) -- same gradients and point_error as for a contiguous copy of the same rays."""
+    d = 2
+    fm = foam_factory(7000, d, 61)
+    cam, rays, start = H.camera_setup(fm, 192, 128)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    full = torch.from_numpy(rays).to(DEV)[None]                      # [1, H, W, 6]
+    view = full[:, 1::2, 0::2, :]
+    assert not view.is_contiguous()
+    st = torch.full(view.shape[:-1], int(start.reshape(-1)[0]), dtype=torch.int64, device=DEV).to(torch.uint32)
+    rng = np.random.default_rng(3)
+    g = torch.from_numpy(rng.normal(size=tuple(view.shape[:-1]) + (4,)).astype(np.float32)).to(DEV)
+    err = torch.from_numpy(rng.uniform(size=tuple(view.shape[:-1]) + (1,)).astype(np.float32)).to(DEV)
+    outs = []
+    for r in (view, view.contiguous()):
+        pipe = _pipeline(d)
+        pipe.record_trail = True
+        pipe.reorder_min_rays = 1024
+        f = pipe.trace_forward(p, a, adj, off, r, st)
+        b = pipe.trace_backward(p, a, adj, off, r, st, f["rgba"], g, ray_error=err)
+        assert pipe.last_backward_replayed is True
+        outs.append((f, b))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0]["rgba"], outs[1][0]["rgba"])
+    for key in ("points_grad", "attr_grad", "point_error"):
+        ok, rel, worst = H.grad_close(outs[0][1][key].cpu().numpy(), outs[1][1][key].cpu().numpy())
+        assert ok and rel < 1e-5, (key, rel, worst)

@@ -450,3 +450,21 @@ def test_traceraysoperator_tells_the_pipeline_whether_a_backward_follows():
     assert real._wants_trail(pts, att) is True          # points only, grad mode irrelevant
     real.backward_hint = False
     assert real._wants_trail(pts.clone().requires_grad_(), att.clone().requires_grad_()) is False
+
+
+def test_a_strided_view_keeps_its_key_across_contiguous_copies():
+    """RadFoamScene.collect_error_map traces rays[:, d0::2, d1::2]: trace_forward and trace_backward each make their own
+    contiguous copy, so the caches that tie the two calls together (ray order, hop trail) are keyed on the caller's view."""
+    import torch
+    from radfoam_amd import pipeline as P
+    base = torch.zeros(1, 8, 8, 6)
+    view = base[:, 1::2, 0::2, :]
+    k1 = P._source_key(view, view.contiguous())
+    k2 = P._source_key(base[:, 1::2, 0::2, :], view.contiguous())      # another view object of the same elements
+    assert k1 == k2
+    assert k1 != P._source_key(base[:, 0::2, 0::2, :], base[:, 0::2, 0::2, :].contiguous())   # other elements
+    base.add_(1.0)                                                       # a write through the base invalidates
+    assert P._source_key(view, view.contiguous()) != k1
+    c = torch.zeros(4, 6)
+    assert P._source_key(c, c.contiguous()) == P._tensor_key(c)         # contiguous inputs: the key they always had
+    assert P._source_key(None, None) is None
