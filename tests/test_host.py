@@ -468,3 +468,19 @@ def test_a_strided_view_keeps_its_key_across_contiguous_copies():
     c = torch.zeros(4, 6)
     assert P._source_key(c, c.contiguous()) == P._tensor_key(c)         # contiguous inputs: the key they always had
     assert P._source_key(None, None) is None
+
+
+def test_tile_order_rules_are_permutations_of_the_static_dealing():
+    """Any block -> tile table must name every tile exactly once (include/radfoam_hip.h: the library does not check)."""
+    import torch
+    from radfoam_amd.pipeline import tile_order
+    for nt, nb in ((3906, 3968), (100, 128), (8160, 8160)):
+        default = torch.arange(nb, dtype=torch.int64)
+        cost = (torch.arange(nt, dtype=torch.int32) * 7919) % 251
+        for rule in ("xcd", "xcd:16", "tail", "tail:64", "global", "chunk:16", "chunk:96", "chunk:1000"):
+            order = tile_order(cost, default, rule)
+            assert order.numel() == nb, rule
+            named = order[order < nt]
+            assert named.numel() == nt and torch.unique(named).numel() == nt, (rule, nt)
+    per_xcd = tile_order(torch.zeros(3906, dtype=torch.int32), torch.arange(3968), "chunk:96").view(-1, 8)
+    assert per_xcd[:96, 3].tolist() == list(range(288, 384))      # XCD 3 starts with one run of 96 consecutive groups
