@@ -134,9 +134,9 @@ def parse_args(argv=None):
                          "what the reference's scene gives its empty cells, scene.py:459): every segment is then 'lit' "
                          "(> 1e-6), as in real training, where softplus never returns exactly 0")
     ap.add_argument("--strict-scan", action="store_true",
-                    help="Pipeline.strict_reference_scan: the reference's per-face quotient scan (tracing_utils.cuh:43-67, "
-                         "rf_launch_opts.forward_mode 3) in forward, backward and render; the CPU baseline then runs the "
-                         "oracle in its 'reference' scan mode, so that the bitwise comparison still holds")
+                    help="Pipeline.strict_reference_scan: every face of every cell divided, the way the reference writes its scan "
+                         "(tracing_utils.cuh:43-67; rf_launch_opts.forward_mode 3) in forward and render -- same results as "
+                         "the default filtered scan (the bitwise comparison with the oracle holds for both), slower")
     ap.add_argument("--forward-mode", type=int, default=None,
                     help="Pipeline.forward_mode (experiments): 1 blocks, 2 eager, 3 = --strict-scan, 4 persistent waves with refill, "
                          "5 eager behind the block-level LDS cell table (auto for sorted flat batches)")
@@ -458,7 +458,7 @@ def run_workload(args, W, env):
         if args.strict_scan:
             pipe.strict_reference_scan = True
             W["custom"] = True
-            W["label"] += ", the reference's quotient scan (forward_mode 3)"
+            W["label"] += ", every face divided (forward_mode 3)"
         if args.grad_pitch is not None:
             pipe.gradient_row_pitch = args.grad_pitch if args.grad_pitch in ("auto", "dense") else int(args.grad_pitch)
     else:
@@ -885,8 +885,6 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
         t2 = time.perf_counter()
         return r.size // 6, t1 - t0, t2 - t1, f, b, (r, s, g, sl, q, dg)
 
-    if args.strict_scan:
-        O.lib().rfo_set_scan_mode(1)      # for the rest of this process: the oracle scans the way the reference writes it
     stride = 24
     n, tf, tb, f, b, smp = run(stride)
     for _ in range(2):   # the pilot is dominated by thread start-up: size the sample in two passes
@@ -952,8 +950,6 @@ def cpu_baseline_render(W, fm, cam, start_np, render_out, strict_scan=False):
     from oracle import oracle as O
 
     cores = int(O.lib().rfo_max_threads())
-    if strict_scan:
-        O.lib().rfo_set_scan_mode(1)
     half_attrs = fm["attributes"].astype(np.float16)     # what benchmark.py feeds the fp16 pipeline (benchmark.py:36)
     diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"])
     start = np.uint32(np.asarray(start_np).reshape(-1)[0])

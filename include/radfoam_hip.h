@@ -90,17 +90,20 @@ typedef struct rf_launch_opts {
     /* any ray scans cell i (the caller zeroes it).  Feeds the compulsory-traffic floor of bench.py's   */
     /* roofline: bytes of the distinct cells, face lists and colour rows a frame touches at least once. */
     uint8_t *visit_marks;
-    uint32_t forward_mode;    /* 0 = auto, 1 = the face scan requests a cell's blocks one at a time (six waves per SIMD  */
-                              /*   hide the latency: large image launches), 2 = the first six blocks are requested        */
-                              /*   together at the hop that enters the cell (four waves per SIMD: flat batches, launches  */
-                              /*   of at most 1024 blocks).  0..2 give the same results bit for bit; auto picks by launch */
-                              /*   shape.  3 = the reference's own scan (tracing_utils.cuh:43-67): every face divided,    */
-                              /*   running minimum of the rounded quotients, v = (P + o/2) - O -- for callers who need    */
-                              /*   the reference's tie-breaking at near-ties; slower (a correctly rounded divide per      */
-                              /*   face).  rf_trace_backward and rf_trace_benchmark honour 3 as well (the replay of a     */
-                              /*   trail must be given the mode its forward ran in); they ignore 0..2.                    */
+    uint32_t forward_mode;    /* HOW the scans of a launch are scheduled; every mode returns the same results, bit for   */
+                              /*   bit: the reference's scan (tracing_utils.cuh:43-67 -- the face with the smallest ROUNDED */
+                              /*   quotient t = ((P + o/2) - O).o / o.d among those with o.d > 0, the lowest index among    */
+                              /*   equal quotients).  0 = auto, 1 = the face scan requests a cell's blocks one at a time    */
+                              /*   (six waves per SIMD hide the latency: large image launches), 2 = the first six blocks    */
+                              /*   are requested together at the hop that enters the cell (four waves per SIMD: flat        */
+                              /*   batches, launches of at most 1024 blocks).  0..2, 4, 5 find the exit by a tournament on   */
+                              /*   cross-multiplied products with a certificate and divide only the winner (cells whose      */
+                              /*   certificate fails -- two exits within 3 floats -- are scanned again by the dividing scan); */
+                              /*   3 = every face of every cell divided, as the reference writes it: the independent         */
+                              /*   instance the others are tested against, 40 % slower.  rf_trace_benchmark honours 3;       */
+                              /*   rf_trace_backward accepts and ignores the field (a trail replays under any mode).         */
                               /*   4 (rf_trace_forward, experiment) = persistent waves that refill their dead lanes from  */
-                              /*   a queue by ballot + prefix count -- same results, slower on every workload measured;   */
+                              /*   a queue by ballot + prefix count -- slower on every workload measured;                  */
                               /*   5 = mode 2 behind a block-level LDS table of cell records + face blocks (what auto     */
                               /*   picks for a flat batch given with a ray_order: its 256-slot groups re-visit cells).    */
     /* Optional: device uint32[rf_launch_blocks(...)], the tile each block of the launch walks -- a 16x16-pixel tile of   */

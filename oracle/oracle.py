@@ -75,20 +75,29 @@ def lib():
 
 
 class scan_mode:
-    """``with O.scan_mode("reference"):`` -- the oracle finds a cell's exit the way the reference writes it
-    (every face divided, running minimum of the rounded quotients, (P + o/2) - O) instead of by the canonical
-    cross-multiplied tournament the HIP kernels implement.  The independent check that the canonical arithmetic
-    did not drift: both modes must agree up to exact-tie flips (tests/test_oracle.py)."""
+    """``with O.scan_mode("filtered") as m:`` -- the oracle EVALUATES a cell's exit the way the HIP kernels do
+    (cross-multiplied tournament over the padded list, bit-distance certificate, dividing scan for contested cells)
+    instead of the way the reference writes it (``"reference"``, the default: every face divided, running minimum of the
+    rounded quotients).  Both compute the same function; ``m.contested`` is the number of cells the filtered evaluation
+    handed to the dividing scan while the block was active."""
 
     def __init__(self, mode):
-        self.mode = {"canonical": 0, "reference": 1}[mode]
+        self.mode = {"reference": 0, "filtered": 1}[mode]
 
     def __enter__(self):
-        self.prev = lib().rfo_get_scan_mode()
-        lib().rfo_set_scan_mode(self.mode)
+        L = lib()
+        L.rfo_get_scan_contested.restype = C.c_uint64
+        self.prev = L.rfo_get_scan_mode()
+        L.rfo_set_scan_mode(self.mode)
+        L.rfo_reset_scan_contested()
         return self
 
+    @property
+    def contested(self):
+        return int(lib().rfo_get_scan_contested())
+
     def __exit__(self, *exc):
+        self.final_contested = self.contested
         lib().rfo_set_scan_mode(self.prev)
         return False
 

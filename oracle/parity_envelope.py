@@ -6,8 +6,9 @@ does not define its fp32 results to the last bit: nvcc contracts a*b+c into FMAs
 the same source is compiled twice (libref.so: no contraction; libref_fma.so: -ffp-contract=fast -mfma, every a*b+c the
 compiler sees fused) and three evaluations are compared on every STRIDE-th row and column of a BASELINE frame:
 
-    oracle   the canonical arithmetic of oracle/rf_oracle.c == the HIP kernels, bit for bit (tests/test_gpu_parity.py,
-             bench.py's whole-frame check)
+    oracle   oracle/rf_oracle.c: the reference's scan (every face's rounded quotient, tracing_utils.cuh:43-67) in the
+             pinned fp32 arithmetic == the HIP kernels, bit for bit (tests/test_gpu_parity.py, bench.py's whole-frame
+             check; the kernels' filtered evaluation of that scan is the same function, tests/test_oracle.py)
     ref      the reference source, no contraction
     ref_fma  the reference source, contracted
 
@@ -17,7 +18,7 @@ of points_grad / attr_grad: overall, and split by linearity (a gradient is a sum
 the rays of the pair that take the same path and the part carried by the flipped rays (a second backward over just
 those).  The pair (ref_fma, ref) is the reference's OWN envelope: what its two legitimate builds disagree about.
 
-What the numbers say (profiles/r03/parity_baseline_scale.json): 0.05-0.2 % of the rays pass a Voronoi edge so closely
+What the numbers say (profiles/r05/parity_baseline_scale.json): 0.05-0.2 % of the rays pass a Voronoi edge so closely
 that the two candidate exits agree to an ulp, and any change of rounding decides them the other way.  Such a ray keeps
 its colour (1e-5 typically, 2e-4 at worst) but deposits its point gradient in other cells, so the OVERALL gradient
 distance is the gradient of the one or two heaviest flipped rays (per-ray norms are heavy-tailed: median 10, max 85 on
@@ -26,13 +27,13 @@ star's 1e-3 by itself.  A factor between two such figures compares two outliers,
 (tests/test_reference_source.py) is therefore: no more flipped rays than 1.5x the reference's own; no more rays
 beyond 1e-4 in rgba than 1.5x its own (floor 2), none beyond 3e-4; on the rays that take the same path, gradients
 within 2e-4 of the nearer of the two builds (the oracle spells its FMAs out, so it sits with the contracted build: 3e-7
-on attr_grad where the uncontracted build is 1.9e-3 away from both); overall gradients within 3x the reference's own
-distance (2x for the quotient scan the reference writes, which the HIP kernels offer as forward_mode 3), and -- the
-north star's words taken literally -- at least 99.99 % of the rays within 1e-4 in rgba and as large a share of the
-gradient elements within 1e-3 as between the reference's own builds (check() below has the list).  Any further change of
-the canonical arithmetic has to pass this before the goldens.
+on attr_grad where the uncontracted build is 1.9e-3 away from both); overall gradients within 2x the reference's own
+distance, and -- the north star's words taken literally -- at least 99.99 % of the rays within 1e-4 in rgba and as
+large a share of the gradient elements within 1e-3 as between the reference's own builds (check() below has the list).
+(Rounds 1-4 shipped a cross-multiplied tournament WITHOUT a certificate as the default scan -- "canonical" -- and
+allowed it 3x; it is gone, and so is the allowance.)
 
-    python -m oracle.parity_envelope [c2] [north-star] [--stride 6] [--out profiles/r04/parity_baseline_scale.json]
+    python -m oracle.parity_envelope [c2] [north-star] [--stride 6] [--out profiles/r05/parity_baseline_scale.json]
 """
 from __future__ import annotations
 
@@ -92,7 +93,7 @@ def _pair(fa, fb, ba, bb, flipped_a, flipped_b):
     return rec
 
 
-def measure(fm, sh_degree, width=1920, height=1080, stride=6, grad_seed=11, with_quotient_mode=True):
+def measure(fm, sh_degree, width=1920, height=1080, stride=6, grad_seed=11):
     """The three evaluations on rows/columns 0, stride, 2*stride, ... of the width x height frame of the SURVEY 8(d)
     camera; returns the record described in the module docstring."""
     from oracle import oracle as O
@@ -116,12 +117,9 @@ def measure(fm, sh_degree, width=1920, height=1080, stride=6, grad_seed=11, with
         if name in ("ref", "ref_fma"):
             with Rf.variant("fma" if name == "ref_fma" else "plain"):
                 return both(Rf.trace_forward, Rf.trace_backward)
-        if name == "oracle_quotient_scan":
-            with O.scan_mode("reference"):
-                return both(O.trace_forward, O.trace_backward)
         return both(O.trace_forward, O.trace_backward)
 
-    names = ["ref", "ref_fma", "oracle"] + (["oracle_quotient_scan"] if with_quotient_mode else [])
+    names = ["ref", "ref_fma", "oracle"]
     fwd, bwd = {}, {}
     for name in names:
         fwd[name], bwd[name] = run(name, rays, g)
@@ -144,9 +142,6 @@ def measure(fm, sh_degree, width=1920, height=1080, stride=6, grad_seed=11, with
         "oracle_vs_ref_fma": pair("oracle", "ref_fma"),
         "ref_fma_vs_ref": pair("ref_fma", "ref"),
     }
-    if with_quotient_mode:
-        rec["oracle_quotient_scan_vs_ref"] = pair("oracle_quotient_scan", "ref")
-        rec["oracle_vs_oracle_quotient_scan"] = pair("oracle", "oracle_quotient_scan")
     rec["seconds"] = round(time.time() - t, 1)
     return rec
 
@@ -155,18 +150,13 @@ def check(rec):
     """The bar (module docstring): the oracle is inside the reference's own envelope.  Returns the list of violations
     (empty = pass).
 
-    Stated literally first: the share of rays whose rgba agrees with the reference source to the north
-    star's 1e-4, and the share of gradient ELEMENTS inside its 1e-3 (tests/helpers.grad_close's bound) -- at least the
-    reference's own share between its two builds, less one part in 10^4.  Then the norms: overall gradient distance at
-    most 2x the reference's own for the scan that follows the reference's evaluation (oracle_quotient_scan == the HIP
-    instances of rf_launch_opts.forward_mode 3), 3x for the canonical divide-free scan (the default instances): it
-    decides near-ties without the quotients' rounding, so it shares fewer of them with either build of the reference
-    (40 / 101 flipped rays against 24 / 67 on the two frames) and the norm is carried by the one or two heaviest of
-    them -- 2.2x the reference's own distance on config 2, 0.4x on the north-star frame (check_frames holds the
-    two together)."""
+    Stated literally first: the share of rays whose rgba agrees with the reference source to the north star's 1e-4, and
+    the share of gradient ELEMENTS inside its 1e-3 (tests/helpers.grad_close's bound) -- at least the reference's own
+    share between its two builds, less one part in 10^4.  Then the norms: overall gradient distance to the nearer build
+    at most 2x the reference's own distance between its builds."""
     bad = []
     own = rec["ref_fma_vs_ref"]
-    pairs = ["oracle_vs_ref", "oracle_vs_ref_fma"] + (["oracle_quotient_scan_vs_ref"] if "oracle_quotient_scan_vs_ref" in rec else [])
+    pairs = ["oracle_vs_ref", "oracle_vs_ref_fma"]
     for other in pairs:
         o = rec[other]
         if o["rays_on_another_path"] > 1.5 * max(own["rays_on_another_path"], 8):
@@ -188,26 +178,22 @@ def check(rec):
             bad.append(("oracle_vs_nearer_build", "same_path_" + k + "_rel_l2", same, 2e-4))
         floor = max(own[k + "_rel_l2"], 1e-4)    # attr_grad: the two builds agree to 1e-5 on some frames
         overall = min(rec["oracle_vs_ref"][k + "_rel_l2"], rec["oracle_vs_ref_fma"][k + "_rel_l2"])
-        if not overall <= 3.0 * floor:
-            bad.append(("oracle_vs_nearer_build", k + "_rel_l2", overall, 3.0 * floor))
-        if "oracle_quotient_scan_vs_ref" in rec:
-            strict = rec["oracle_quotient_scan_vs_ref"][k + "_rel_l2"]
-            if not strict <= 2.0 * floor:
-                bad.append(("oracle_quotient_scan_vs_ref", k + "_rel_l2", strict, 2.0 * floor))
+        if not overall <= 2.0 * floor:
+            bad.append(("oracle_vs_nearer_build", k + "_rel_l2", overall, 2.0 * floor))
     return bad
 
 
 def check_frames(records):
-    """Across frames (a list of measure() records): the geometric mean of (canonical scan's overall points_grad distance
-    to the nearer build) / (the reference's own distance between its builds) must not exceed 1.5 -- one frame's ratio
-    compares two outliers, the mean over frames says whether the canonical scan is systematically further from the
-    reference than the reference is from itself.  Returns (ratios, violations)."""
+    """Across frames (a list of measure() records): (the oracle's overall points_grad distance to the nearer build) / (the
+    reference's own distance between its builds) per frame -- one frame's ratio compares two outliers, so the geometric
+    mean over frames is held to 1.0: the scan is not systematically further from the reference than the reference is
+    from itself.  Returns (ratios, violations)."""
     ratios = []
     for rec in records:
         own = max(rec["ref_fma_vs_ref"]["points_grad_rel_l2"], 1e-4)
         ratios.append(min(rec["oracle_vs_ref"]["points_grad_rel_l2"], rec["oracle_vs_ref_fma"]["points_grad_rel_l2"]) / own)
     gm = float(np.exp(np.mean(np.log(np.maximum(ratios, 1e-12))))) if ratios else 0.0
-    return ratios, ([("canonical_over_own_geomean", gm, 1.5)] if gm > 1.5 else [])
+    return ratios, ([("oracle_over_own_geomean", gm, 1.0)] if gm > 1.0 else [])
 
 
 def load_foam(name, build_if_missing=True):
@@ -232,7 +218,7 @@ def main(argv):
         result[name] = rec
         print(name, json.dumps(rec, indent=1))
     ratios, bad = check_frames(list(result.values()))
-    print("canonical scan / reference's own overall points_grad distance per frame:", [round(r, 3) for r in ratios], bad)
+    print("oracle / reference's own overall points_grad distance per frame:", [round(r, 3) for r in ratios], bad)
     if out:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         with open(out, "w") as f:

@@ -64,12 +64,21 @@ typedef struct {
     uint64_t segments_lit;    /* ... with density > 1e-6 (SH row needed)     */
 } rfo_stats;
 
-/* How the nearest exit of a cell is found: 0 = canonical (cross-multiplied pair tournament, one divide per cell:
- * what the HIP kernels implement and are compared bit for bit against), 1 = the reference's own order (every face
- * divided, running minimum of rounded quotients, v = (P + o/2) - O).  Process-global, set by the tests only. */
+/* How the nearest exit of a cell is EVALUATED (the function is always the reference's, rf_oracle_body.inc: scan_cell):
+ * 0 = the way the reference writes it (every face divided, running minimum of rounded quotients); 1 = the way the HIP
+ * kernels do (cross-multiplied tournament + certificate, dividing scan for contested cells) -- bit-identical by
+ * construction, which tests/test_oracle.py checks over whole frames.  Process-global, set by the tests only.
+ * rfo_scan_contested counts the cells mode 1 handed to the dividing scan. */
+/* products at most this many floats apart do not decide a comparison (rf_kernels.hip: kTieUlps, with the derivation) */
+#ifndef RFO_TIE_ULPS
+#define RFO_TIE_ULPS 3u
+#endif
 static int rfo_scan_mode = 0;
+static uint64_t rfo_scan_contested = 0;
 void rfo_set_scan_mode(int mode) { rfo_scan_mode = mode == 1 ? 1 : 0; }
 int rfo_get_scan_mode(void) { return rfo_scan_mode; }
+uint64_t rfo_get_scan_contested(void) { return rfo_scan_contested; }
+void rfo_reset_scan_contested(void) { rfo_scan_contested = 0; }
 
 /* rfo_trace_paths: per-thread recorder of a ray's walk (scheduling studies of the kernels: scripts/model_*.py) */
 static _Thread_local uint32_t *rfo_path_cells = NULL;

@@ -111,7 +111,6 @@ struct BwdParams {
     const uint32_t *trail;
     const uint32_t *trail_hops;
     uint32_t trail_cap, trail_slots;
-    uint32_t strict;             // the forward of these rays ran the reference's quotient scan (forward_mode 3)
     uint32_t attr_pitch;         // floats between two rows of attr_grad (>= A; rf_launch_opts.attr_grad_pitch)
     unsigned long long *stats;   // optional scatter counters (experiments): [0] row flushes [1] values flushed
                                  // [2] lane contributions that bypassed the block cache [3] cached lane contributions
@@ -214,17 +213,15 @@ struct ScanResult {
     uint32_t k;     // winning face, relative to the cell's first face; kNone if no exit
 };
 
-// t of the ray/bisector hit for one face with offset o; dp > 0 <=> the ray leaves through it
-__device__ __forceinline__ void face_hit(float ox, float oy, float oz, float Px, float Py, float Pz,
-                                         float Ox, float Oy, float Oz, float dx, float dy, float dz,
-                                         float &dp, float &t) {
-    dp = dot3(ox, oy, oz, dx, dy, dz);
-    // v = (P - O) + o/2: the cell-minus-origin term is the same for every face of the cell, so the scan forms
-    // it once per step (canonical order; the reference writes (P + o/2) - O)
-    float vx = fma_(ox, 0.5f, Px - Ox);
-    float vy = fma_(oy, 0.5f, Py - Oy);
-    float vz = fma_(oz, 0.5f, Pz - Oz);
-    t = dot3(vx, vy, vz, ox, oy, oz) / dp;
+// t of the ray/bisector hit for one face with offset o, as tracing_utils.cuh:57-60 forms it (and as the scans below do):
+// what the trail replay recomputes for the face a hop crossed -- the same float the forward's scan produced
+__device__ __forceinline__ float face_hit(float ox, float oy, float oz, float Px, float Py, float Pz,
+                                          float Ox, float Oy, float Oz, float dx, float dy, float dz) {
+    const float dp = dot3(ox, oy, oz, dx, dy, dz);
+    const float vx = fma_(ox, 0.5f, Px) - Ox;
+    const float vy = fma_(oy, 0.5f, Py) - Oy;
+    const float vz = fma_(oz, 0.5f, Pz) - Oz;
+    return dot3(vx, vy, vz, ox, oy, oz) / dp;
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -238,98 +235,201 @@ struct __attribute__((aligned(8))) GeoZ {
     uint32_t z01, z23;
 };
 
-// Nearest exit of the ray from the cell whose `cnt` (a multiple of 4, padding included) face
-// entries start at `blk` in the geo table; the first minimum wins, like the reference.  Four faces per
-// iteration, branch-free, two at a time in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32); a block arrives as
-// one 16-byte and one 8-byte load (blocks are 8-byte aligned, which this hardware serves --
-// scripts/probe/unaligned.hip).  Padding entries have a zero offset: dp = 0, never a candidate.
+// ---- the face scan ----------------------------------------------------------------------------------------------
+// WHAT is computed is the reference's scan, tracing_utils.cuh:43-67, to the bit: per face o (fp16 -> fp32)
+//     dp = o.d      v = (P + o/2) - O      t = (v.o) / dp  (IEEE divide)      take if dp > 0 && t < t_1
+// i.e. the exit is the face with the smallest ROUNDED quotient among those with dp > 0, the lowest index among equal
+// quotients, and t_1 is that rounded quotient.  This is a total preorder on the faces, so the result does not depend on
+// the order in which they are examined -- which is what lets the kernels find it without dividing every face:
 //
-// No face is divided.  t = num/dp of two faces is compared by cross-multiplication (num_a*dp_b < num_b*dp_a,
-// both dp > 0: one rounding per product), the running best is kept as the fraction (nb, db), and only the
-// winner's quotient is formed, once per cell, by an IEEE divide -- the canonical evaluation of DESIGN.md
-// section 2, which the CPU checker of the test-suite implements step for step.  Faces go in pairs: the nearer of
-// the pair (the first on a tie) is found by one comparison and tested against the running best by another.  Per pair
-// 2 packed multiplies, 4 compares and 6 selects instead of 2 v_rcp_f32 + 7 packed + 4 compares + 4 selects for two
-// expanded divides.
+//   filter   two faces a, b with dp > 0 are compared by cross-multiplication, p1 = RN(num_a * dp_b) against
+//            p2 = RN(num_b * dp_a) (one packed operation); num and dp are the reference's own floats (same association,
+//            same dot-product order as scan_faces_strict below).  Let D = |bits(p1) - bits(p2)|, the number of floats
+//            from one product to the other.  If D >= 4 the order of p1 and p2 is the STRICT order of the two rounded
+//            quotients RN(num_a/dp_a), RN(num_b/dp_b):  |p1 - p2| >= D ulp(p) (the smaller ulp when they straddle a
+//            binade), each product is within half an ulp of its exact value, so the exact products differ by at least
+//            (D - 1.5) ulp(p) >= 2.5 * 2^-24 relative; the exact quotients num_a/dp_a and num_b/dp_b differ by the same
+//            relative amount (divide both products by dp_a dp_b), which is more than one ulp of a quotient (at most
+//            2^-23 relative), and two reals more than an ulp apart round to different floats in their own order.
+//            (Zero and subnormal products: same argument with absolute spacings, 2^-149.  Opposite signs: D >= 2^23.
+//            Assumes nonzero point / origin coordinates of magnitude >= 2^-40, so that a nonzero num is >= 2^-87 and no
+//            QUOTIENT is subnormal.)  A pairwise tournament over such comparisons (the nearer face of a pair, then
+//            against the running best; earlier faces win ties) therefore returns the reference's face whenever NO
+//            comparison it made had D <= kTieUlps = 3;
+//   certify  the scan keeps the minimum D over all its comparisons (v_sad_u32 + v_min3_u32: three instructions per pair
+//            of faces).  Products are formed as fma(x, y, +0), so that a zero product is always +0 and two zero
+//            products are 0 apart;
+//   resolve  a cell whose minimum is <= kTieUlps is scanned again by scan_faces_strict, which divides every face as the
+//            reference does.  How often: the exits of a cell differ by (cell size / distance from the ray origin)
+//            relative, 1/230 on the 2 M-point benchmark foam, so two of them fall within +-3 floats of each other in about
+//            4 cell scans of 10^4 (measured by the CPU checker's mirror of this evaluation, the test-suite: 1.3e-4
+//            at 60 k points).  Only the winner of an uncontested scan is divided, once.
+//
+// Face lists are padded to a multiple of four entries with copies of the block's first real face at 2x, 4x, 8x its
+// offset (pad_offset, prepare kernels): a bisector twice / four / eight times as far along the same normal has the same
+// sign of dp and a quotient that is never smaller (every rounding on the way is monotone), and a higher index, so a
+// padding entry never wins -- under the reference's rule itself, no special case in any scan.  (An all-zero entry, used
+// when the doubled offset would overflow fp16, has dp = 0 and is no candidate either; it merely sends the cell to the
+// dividing scan, since two zero products are 0 apart.)
+//
+// Four faces per iteration, branch-free, two at a time in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32); a block arrives as
+// one 16-byte and one 8-byte load (blocks are 8-byte aligned, which this hardware serves -- scripts/probe/unaligned.hip).
 // The winner is tracked relative to the block being scanned (`rel`, inline constants 0..3) and rebased once per
 // iteration, instead of materialising k+j per face.
 // Measured out for whole frames in round 3 (profiles/r03/c_ab_scan_pipe_*; the code is in commit 488b7a4): requesting
 // the first block of the next cell at hop time, from the link just read (forward 4.75 ms against 4.67), and on top of
-// that software-pipelining the block loop with inline-asm loads and an explicit s_waitcnt -- left to itself the optimiser
-// rotates a source-level pipeline back into load-wait-compute -- (4.83 ms: the six register copies and the address
-// select per iteration cost more issue slots than the exposed L1 latency they hide; a whole frame is issue-bound, six
-// waves per SIMD already cover the rest).  Flat batches and small launches are not: scan_faces_eager below.
+// that software-pipelining the block loop with inline-asm loads and an explicit s_waitcnt (4.83 ms: a whole frame is
+// issue-bound, six waves per SIMD already cover the latency).  Flat batches and small launches are not: scan_faces_eager.
+// History: rounds 1-4 shipped a different evaluation as the default ("canonical": v = (P - O) + o/2, the
+// cross-multiplied tournament WITHOUT the certificate, i.e. near-ties decided by the rounded products) and this one only
+// as the dividing instance; profiles/HISTORY.md has its numbers.
+constexpr uint32_t kTieUlps = 3;    // see above; must stay below scan_block's bias (64)
+
 __device__ __forceinline__ void load_geo_block(const uint32_t *src, GeoXY &A, GeoZ &B) {
     A = *reinterpret_cast<const GeoXY *>(src);
     B = *reinterpret_cast<const GeoZ *>(src + 4);
 }
 
-// running state of a scan: best exit so far as the fraction best.y / best.x (inf/1 loses against any valid face) and
-// its position relative to the current block
-struct ScanState {
-    v2f best;
-    int rel;
-};
-
-// the four faces of one block against the running best
-__device__ __forceinline__ void scan_block(ScanState &S, const GeoXY &A, const GeoZ &B, v2f C2x, v2f C2y, v2f C2z,
-                                           v2f d2x, v2f d2y, v2f d2z) {
-    const v2f half2 = {0.5f, 0.5f};
-    S.rel -= 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint32_t wx = h ? A.x23 : A.x01, wy = h ? A.y23 : A.y01, wz = h ? B.z23 : B.z01;
-        const v2f ox = {half_lo(wx), half_hi(wx)};
-        const v2f oy = {half_lo(wy), half_hi(wy)};
-        const v2f oz = {half_lo(wz), half_hi(wz)};
-        // dp = fma(ox,dx, fma(oy,dy, oz*dz))
-        const v2f dpp = fma2(ox, d2x, fma2(oy, d2y, oz * d2z));
-        // v = (P - O) + o/2 ; num = fma(vx,ox, fma(vy,oy, vz*oz))
-        const v2f vx = fma2(ox, half2, C2x);
-        const v2f vy = fma2(oy, half2, C2y);
-        const v2f vz = fma2(oz, half2, C2z);
-        const v2f num = fma2(vx, ox, fma2(vy, oy, vz * oz));
-        // the nearer face of the pair (the first on a tie, or when the second is no exit) ...
-        const v2f c = __builtin_shufflevector(num, num, 1, 0) * dpp;    // {num1*dp0, num0*dp1}
-        // (bitwise, not short-circuit, logic on the predicates: everything is computed for both faces anyway and
-        // the compiler must not turn the selection into branches)
-        const bool v0 = dpp.x > 0.0f, v1 = dpp.y > 0.0f, lt10 = c.x < c.y;
-        const bool w1 = v1 & (!v0 | lt10);
-        const v2f cand = {w1 ? num.y : num.x, w1 ? dpp.y : dpp.x};      // (num, dp) of the pair's winner
-        // ... against the running best, kept as the adjacent pair (db, nb): one packed multiply forms both products
-        const v2f ab = cand * S.best;                                    // {num_w*db, dp_w*nb}
-        const bool take = (w1 | v0) & (ab.x < ab.y);
-        S.best.x = take ? cand.y : S.best.x;
-        S.best.y = take ? cand.x : S.best.y;
-        S.rel = take ? (w1 ? 2 * h + 1 : 2 * h) : S.rel;
-    }
+// |bits(a) - bits(b)| + bias as unsigned integers: the number of floats between two products of the same sign, huge for
+// products of opposite signs, 0 for two (+)zeros; `bias` lifts the lanes that sit a block out above any threshold
+__device__ __forceinline__ uint32_t bit_distance(float a, float b, uint32_t bias) {
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(bias));
+    return r;
 }
 
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t m = a < b ? a : b;
+    return m < c ? m : c;
+}
+
+// the ray and the cell as the packed scan wants them (every scalar broadcast to both halves of a register pair)
+struct ScanRay {
+    v2f Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz;
+};
+
+__device__ __forceinline__ ScanRay scan_ray(float Px, float Py, float Pz, float Ox, float Oy, float Oz, float dx, float dy,
+                                            float dz) {
+    ScanRay R;
+    R.Px = {Px, Px}; R.Py = {Py, Py}; R.Pz = {Pz, Pz};
+    R.Ox = {Ox, Ox}; R.Oy = {Oy, Oy}; R.Oz = {Oz, Oz};
+    R.dx = {dx, dx}; R.dy = {dy, dy}; R.dz = {dz, dz};
+    return R;
+}
+
+// running state of a scan: best exit so far as the fraction best.y / best.x (inf/1 loses against any valid face), where
+// it is, and the smallest bit distance of any comparison made so far.  The winner's position is kept as the entry number
+// of its block (a register, rewritten once per block) and its two low bits as WAVE MASKS in scalar registers, updated by
+// scalar instructions from the comparison masks -- four vector instructions per block fewer than selecting an index per
+// pair, on a kernel bound by vector issue.
+struct ScanState {
+    v2f best;
+    uint32_t blk;              // first entry of the block that holds the best exit so far; kNone: none yet
+    unsigned long long b0, b1; // per lane (bit = lane): bits 0 and 1 of its position inside that block
+    uint32_t tie;
+};
+
+__device__ __forceinline__ void scan_begin(ScanState &S) {
+    S.best = {1.0f, __builtin_inff()};
+    S.blk = kNone;
+    S.b0 = S.b1 = 0ull;
+    S.tie = 0xFFFFFFFFu;
+}
+
+// num and dp of the two faces whose fp16 offsets sit in the halves of (wx, wy, wz), as tracing_utils.cuh:57-60 forms
+// them: every packed lane is an independent IEEE operation, the same roundings as the scalar form
+__device__ __forceinline__ void face_pair(uint32_t wx, uint32_t wy, uint32_t wz, const ScanRay &R, v2f &num, v2f &dpp) {
+    const v2f half2 = {0.5f, 0.5f};
+    const v2f ox = {half_lo(wx), half_hi(wx)};
+    const v2f oy = {half_lo(wy), half_hi(wy)};
+    const v2f oz = {half_lo(wz), half_hi(wz)};
+    dpp = fma2(ox, R.dx, fma2(oy, R.dy, oz * R.dz));
+    const v2f vx = fma2(ox, half2, R.Px) - R.Ox;      // (P + o/2) - O; o/2 is exact, so P + o/2 is one rounding
+    const v2f vy = fma2(oy, half2, R.Py) - R.Oy;
+    const v2f vz = fma2(oz, half2, R.Pz) - R.Oz;
+    num = fma2(vx, ox, fma2(vy, oy, vz * oz));
+}
+
+// The four faces of the block whose first entry is `k` (wave-uniform) against the running best.  Executed by the whole
+// wave; `act` = the lanes whose list has this block (the others hold stale data: they take nothing and their distances are
+// biased away).  Every predicate is a wave mask (v_cmp writes one), combined by scalar instructions and applied by
+// v_cndmask: the selection costs the vector unit four compares and four selects per pair, nothing else.
+__device__ __forceinline__ void scan_block(ScanState &S, uint32_t k, unsigned long long act, const GeoXY &A, const GeoZ &B,
+                                           const ScanRay &R) {
+    const v2f zero2 = {0.0f, 0.0f};
+    const uint32_t bias = __builtin_amdgcn_inverse_ballot_w64(act) ? 0u : 64u;   // (an inline constant) > kTieUlps
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        v2f num, dpp;
+        face_pair(h ? A.x23 : A.x01, h ? A.y23 : A.y01, h ? B.z23 : B.z01, R, num, dpp);
+        // the nearer face of the pair (the first on a tie, or when the second is no exit) ...
+        const v2f c = fma2(__builtin_shufflevector(num, num, 1, 0), dpp, zero2);    // {num1*dp0, num0*dp1}
+        const unsigned long long v0 = ballot(dpp.x > 0.0f), v1 = ballot(dpp.y > 0.0f), lt10 = ballot(c.x < c.y);
+        const unsigned long long w1m = v1 & ~(v0 & ~lt10);
+        const bool w1 = __builtin_amdgcn_inverse_ballot_w64(w1m);
+        const v2f cand = {w1 ? num.y : num.x, w1 ? dpp.y : dpp.x};      // (num, dp) of the pair's winner
+        // ... against the running best, kept as the adjacent pair (db, nb): one packed operation forms both products
+        const v2f ab = fma2(cand, S.best, zero2);                        // {num_w*db, dp_w*nb}
+        const unsigned long long tm = (w1m | v0) & ballot(ab.x < ab.y) & act;
+        const bool take = __builtin_amdgcn_inverse_ballot_w64(tm);
+        S.best.x = take ? cand.y : S.best.x;
+        S.best.y = take ? cand.x : S.best.y;
+        S.b0 = (S.b0 & ~tm) | (w1m & tm);
+        S.b1 = h ? (S.b1 | tm) : (S.b1 & ~tm);
+        any |= tm;
+        S.tie = min3u(S.tie, bit_distance(c.x, c.y, bias), bit_distance(ab.x, ab.y, bias));
+    }
+    S.blk = __builtin_amdgcn_inverse_ballot_w64(any) ? k : S.blk;
+}
+
+__device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uint32_t cnt, float Px, float Py, float Pz,
+                                                        float Ox, float Oy, float Oz, float dx, float dy, float dz);
+
+// what a finished tournament found; `contested`: some comparison was too close for the products to decide
+__device__ __forceinline__ ScanResult scan_end(const ScanState &S, bool &contested) {
+    ScanResult r;
+    const bool found = S.blk != kNone;
+    const uint32_t pos = (__builtin_amdgcn_inverse_ballot_w64(S.b1) ? 2u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(S.b0) ? 1u : 0u);
+    r.k = found ? S.blk + pos : kNone;
+    r.t1 = found ? S.best.y / S.best.x : __builtin_inff();
+    // a quotient that overflows is no exit for the reference either (t < inf fails); nothing can be nearer: the tournament's
+    // winner has the smallest exact quotient
+    if (!(r.t1 < __builtin_inff())) r.k = kNone;
+    contested = S.tie <= kTieUlps;
+    return r;
+}
+
+// Nearest exit of the ray from the cell whose `cnt` (a multiple of 4, padding included) face entries start at `blk` in
+// the geo table.
 __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t cnt, float Px, float Py,
                                                  float Pz, float Ox, float Oy, float Oz, float dx,
                                                  float dy, float dz) {
-    ScanResult r;
-    constexpr int kUnset = -0x40000000;
     ScanState S;
-    S.rel = kUnset;
-    S.best = {1.0f, __builtin_inff()};
-    const float cx = Px - Ox, cy = Py - Oy, cz = Pz - Oz;   // once per cell, not per face
-    const v2f C2x = {cx, cx}, C2y = {cy, cy}, C2z = {cz, cz};
-    const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
+    scan_begin(S);
+    const ScanRay R = scan_ray(Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
-    for (uint32_t k = 0; k < cnt; k += 4) {
-        GeoXY A;
-        GeoZ B;
-        load_geo_block(src, A, B);
-        src += 6;
-        scan_block(S, A, B, C2x, C2y, C2z, d2x, d2y, d2z);
+    // the loop is wave-uniform (it runs while any lane has a block left; a lane without one sits out): the winner's
+    // position bits are wave masks, i.e. scalar values, which a loop that lanes LEAVE at different trips would force into
+    // vector registers
+    GeoXY A = {0u, 0u, 0u, 0u};
+    GeoZ B = {0u, 0u};
+    uint32_t k = 0;
+    unsigned long long act = ballot(0u < cnt);
+    if (act != 0ull) {
+        do {
+            if (__builtin_amdgcn_inverse_ballot_w64(act)) {
+                load_geo_block(src, A, B);
+                src += 6;
+            }
+            scan_block(S, k, act, A, B, R);
+            k += 4;
+            act = ballot(k < cnt);
+        } while (act != 0ull);
     }
-    const int rel = S.rel;
-    const v2f best = S.best;
-    // after a lane's last iteration its block base is cnt - 4
-    const bool found = rel > kUnset / 2;
-    r.k = found ? (cnt - 4u) + (uint32_t)rel : kNone;
-    r.t1 = found ? best.y / best.x : __builtin_inff();
+    bool contested;
+    ScanResult r = scan_end(S, contested);
+    if (contested) r = scan_faces_strict(blk, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
     return r;
 }
 
@@ -349,35 +449,34 @@ __device__ __forceinline__ void load_geo_blocks(const uint16_t *geo, uint32_t fi
     for (int i = 0; i < K; ++i) load_geo_block(src + 6u * (last < (uint32_t)i ? last : (uint32_t)i), G.A[i], G.B[i]);
 }
 
-// scan_faces with the first K blocks already in registers (or on their way); same arithmetic in the same order
+// scan_faces with the first K blocks already in registers (or on their way); same result
 template <int K>
 __device__ __forceinline__ ScanResult scan_faces_eager(const GeoBlocks<K> &G, const uint16_t *blk, uint32_t cnt, float Px,
                                                        float Py, float Pz, float Ox, float Oy, float Oz, float dx,
                                                        float dy, float dz) {
-    ScanResult r;
-    constexpr int kUnset = -0x40000000;
     ScanState S;
-    S.rel = kUnset;
-    S.best = {1.0f, __builtin_inff()};
-    const float cx = Px - Ox, cy = Py - Oy, cz = Pz - Oz;
-    const v2f C2x = {cx, cx}, C2y = {cy, cy}, C2z = {cz, cz};
-    const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
+    scan_begin(S);
+    const ScanRay R = scan_ray(Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
 #pragma unroll
     for (int i = 0; i < K; ++i)
-        if ((uint32_t)(4 * i) < cnt) scan_block(S, G.A[i], G.B[i], C2x, C2y, C2z, d2x, d2y, d2z);
+        scan_block(S, (uint32_t)(4 * i), ballot((uint32_t)(4 * i) < cnt), G.A[i], G.B[i], R);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(blk) + 6 * K;
-    for (uint32_t k = 4u * K; k < cnt; k += 4) {
-        GeoXY A;
-        GeoZ B;
-        load_geo_block(src, A, B);
-        src += 6;
-        scan_block(S, A, B, C2x, C2y, C2z, d2x, d2y, d2z);
+    GeoXY A = {0u, 0u, 0u, 0u};
+    GeoZ B = {0u, 0u};
+    uint32_t k = 4u * K;
+    unsigned long long act = ballot(k < cnt);
+    while (act != 0ull) {
+        if (__builtin_amdgcn_inverse_ballot_w64(act)) {
+            load_geo_block(src, A, B);
+            src += 6;
+        }
+        scan_block(S, k, act, A, B, R);
+        k += 4;
+        act = ballot(k < cnt);
     }
-    const int rel = S.rel;
-    const v2f best = S.best;
-    const bool found = rel > kUnset / 2;
-    r.k = found ? (cnt - 4u) + (uint32_t)rel : kNone;
-    r.t1 = found ? best.y / best.x : __builtin_inff();
+    bool contested;
+    ScanResult r = scan_end(S, contested);
+    if (contested) r = scan_faces_strict(blk, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
     return r;
 }
 
@@ -453,21 +552,17 @@ __device__ __forceinline__ void cache_fill(CellEntry<K> *cache, uint32_t entries
     v->tag = version | (unsigned long long)cell;
 }
 
-// The reference's own evaluation of a scan (tracing_utils.cuh:43-67), selectable as rf_launch_opts.forward_mode = 3:
-// v = (P + o/2) - O, EVERY face divided (IEEE), a running minimum of the rounded quotients, strict '<' (the first
-// minimum wins).  Same face table, same dot-product association as everywhere else; bit-identical to the CPU checker's
-// "reference" scan mode.  It exists for callers who need the reference's tie-breaking (the canonical scan above decides
-// a near-tie by cross-multiplication, i.e. without the rounding of the two quotients; DESIGN.md section 2 has both
-// distances to the reference source) and costs a correctly rounded divide per face.
+// The reference's scan evaluated the way the reference writes it (tracing_utils.cuh:43-67): EVERY face divided (IEEE), a
+// running minimum of the rounded quotients, strict '<' (the first minimum wins).  It resolves the contested cells of the
+// scans above, and is selectable for whole launches as rf_launch_opts.forward_mode = 3 -- the independent instance the
+// filtered scan is tested against bit for bit (tests/test_gpu_parity.py); a correctly rounded divide per face makes it
+// 40 % slower on a frame.
 __device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uint32_t cnt, float Px, float Py, float Pz,
                                                         float Ox, float Oy, float Oz, float dx, float dy, float dz) {
     ScanResult r;
     r.t1 = __builtin_inff();
     r.k = kNone;
-    const v2f half2 = {0.5f, 0.5f};
-    const v2f P2x = {Px, Px}, P2y = {Py, Py}, P2z = {Pz, Pz};
-    const v2f O2x = {Ox, Ox}, O2y = {Oy, Oy}, O2z = {Oz, Oz};
-    const v2f d2x = {dx, dx}, d2y = {dy, dy}, d2z = {dz, dz};
+    const ScanRay R = scan_ray(Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
     for (uint32_t k = 0; k < cnt; k += 4) {
         GeoXY A;
@@ -476,17 +571,9 @@ __device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uin
         src += 6;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            // two faces per packed instruction up to the quotients (the same roundings as the scalar form: every packed
-            // lane is an independent IEEE operation); the divides and the running minimum stay per face, in list order
-            const uint32_t wx = h ? A.x23 : A.x01, wy = h ? A.y23 : A.y01, wz = h ? B.z23 : B.z01;
-            const v2f ox = {half_lo(wx), half_hi(wx)};
-            const v2f oy = {half_lo(wy), half_hi(wy)};
-            const v2f oz = {half_lo(wz), half_hi(wz)};
-            const v2f dpp = fma2(ox, d2x, fma2(oy, d2y, oz * d2z));
-            const v2f vx = (P2x + ox * half2) - O2x;
-            const v2f vy = (P2y + oy * half2) - O2y;
-            const v2f vz = (P2z + oz * half2) - O2z;
-            const v2f num = fma2(vx, ox, fma2(vy, oy, vz * oz));
+            v2f num, dpp;
+            face_pair(h ? A.x23 : A.x01, h ? A.y23 : A.y01, h ? B.z23 : B.z01, R, num, dpp);
+            // the divides and the running minimum stay per face, in list order
             const float t0 = num.x / dpp.x, t1 = num.y / dpp.y;
             const bool take0 = (dpp.x > 0.0f) & (t0 < r.t1);
             r.t1 = take0 ? t0 : r.t1;
@@ -497,16 +584,6 @@ __device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uin
         }
     }
     return r;
-}
-
-// t of the crossed face as scan_faces_strict forms it (the trail replay of a strict forward must reproduce that float)
-__device__ __forceinline__ float face_hit_strict(float ox, float oy, float oz, float Px, float Py, float Pz, float Ox,
-                                                 float Oy, float Oz, float dx, float dy, float dz) {
-    const float dp = dot3(ox, oy, oz, dx, dy, dz);
-    const float vx = (Px + ox * 0.5f) - Ox;
-    const float vy = (Py + oy * 0.5f) - Oy;
-    const float vz = (Pz + oz * 0.5f) - Oz;
-    return dot3(vx, vy, vz, ox, oy, oz) / dp;
 }
 
 // fp16-rounded offset from cell p to its neighbour q, as the face tables hold it (pack_diff)
@@ -1464,10 +1541,7 @@ __global__ __launch_bounds__(kBlock) void backward_kernel(BwdParams p) {
         sr.t1 = __builtin_inff();
         sr.k = kNone;
         if (alive) {
-            if (p.strict)
-                sr = scan_faces_strict(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
-            else
-                sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
+            sr = scan_faces(fv.geo + (size_t)nb * 3u, cnt, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
             if (sr.k == kNone) alive = false;
         }
         uint32_t nxt = 0, nnb = 0, ncnt = 0;
@@ -1562,10 +1636,9 @@ __global__ __launch_bounds__(kBlock) void backward_replay_kernel(BwdParams p) {
         float t1 = 0.0f;
         if (alive) {
             nhead = q0;
-            float ox, oy, oz, dp;
+            float ox, oy, oz;
             face_offset(head, nhead, ox, oy, oz);
-            face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
-            if (p.strict) t1 = face_hit_strict(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
+            t1 = face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
         }
         if (alive) {
             if (t1 > R.t0) {
@@ -1807,10 +1880,9 @@ struct TrailWalker {
         float t1 = 0.0f;
         if (alive) {
             nhead = q0;
-            float ox, oy, oz, dp;
+            float ox, oy, oz;
             face_offset(head, nhead, ox, oy, oz);
-            face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, dp, t1);
-            if (p.strict) t1 = face_hit_strict(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
+            t1 = face_hit(ox, oy, oz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz);
         }
 #ifdef RF_EXPERIMENT_SECTIONS
         asm volatile("" : "+v"(t1));
@@ -2260,6 +2332,20 @@ __device__ __forceinline__ uint2 pack_diff(float dx, float dy, float dz) {
     return make_uint2(lo, hi);
 }
 
+// Padding entry at position j (1..3) of a list's last block, whose first entry (always a real face) has the fp16 offset
+// (hx, hy, hz): the same offset times 2^j (exact in fp16) -- a bisector 2^j times as far along the same normal, which the
+// scan can treat like any other face and which never wins (see "the face scan" above).  All-zero when the scaled offset
+// leaves the fp16 range (offsets of 8190 and more: not a foam the fp16 table could hold anyway).
+__device__ __forceinline__ void pad_offset(uint16_t hx, uint16_t hy, uint16_t hz, uint32_t j, uint16_t &px, uint16_t &py,
+                                           uint16_t &pz) {
+    const float k = (float)(1u << j);
+    px = float_to_half_bits(half_lo(hx) * k);
+    py = float_to_half_bits(half_lo(hy) * k);
+    pz = float_to_half_bits(half_lo(hz) * k);
+    const bool over = ((px & 0x7C00u) == 0x7C00u) | ((py & 0x7C00u) == 0x7C00u) | ((pz & 0x7C00u) == 0x7C00u);
+    if (over) px = py = pz = (uint16_t)0;
+}
+
 // ---- padded offsets: poff[i] = sum_{j<i} round_up4(offsets[j+1] - offsets[j]) -------------------
 // Three small launches: per-chunk sums (kScanChunk cells per 256-thread block, 4 cells per
 // thread), one block scanning the chunk sums, then the per-cell exclusive scan inside each chunk.
@@ -2378,9 +2464,11 @@ __global__ __launch_bounds__(256) void prepare_foam_kernel(
         const uint32_t j = f - off[lo];
         uint2 d = make_uint2(0u, 0u);
         Link lk = {0u, 0u, 0u};
-        if (j < csr[lo + 1] - csr[lo]) {
+        const bool real = j < csr[lo + 1] - csr[lo];
+        {
+            // a padding entry takes the offset of its block's first entry (a real face), scaled
             const uint32_t i = c0 + lo;
-            const uint32_t src = csr[lo] + j;
+            const uint32_t src = csr[lo] + (real ? j : (j & ~3u));
             const uint32_t q = adj[src];
             if (ext_diff) {
                 d = ext_diff[src];
@@ -2389,17 +2477,23 @@ __global__ __launch_bounds__(256) void prepare_foam_kernel(
                 const float qx = points[3 * (size_t)q], qy = points[3 * (size_t)q + 1], qz = points[3 * (size_t)q + 2];
                 d = pack_diff(qx - px, qy - py, qz - pz);
             }
-            const uint32_t qb = poff[q];
-            lk.nbr = q;
-            lk.first = qb;
-            lk.count = poff[q + 1] - qb;
+            if (real) {
+                const uint32_t qb = poff[q];
+                lk.nbr = q;
+                lk.first = qb;
+                lk.count = poff[q + 1] - qb;
+            } else {
+                uint16_t hx, hy, hz;
+                pad_offset((uint16_t)(d.x & 0xFFFFu), (uint16_t)(d.x >> 16), (uint16_t)(d.y & 0xFFFFu), j & 3u, hx, hy, hz);
+                d = make_uint2((uint32_t)hx | ((uint32_t)hy << 16), (uint32_t)hz);
+            }
         }
         uint16_t *g = geo + (size_t)(f >> 2) * 12u + (f & 3u);
         g[0] = (uint16_t)(d.x & 0xFFFFu);
         g[4] = (uint16_t)(d.x >> 16);
         g[8] = (uint16_t)(d.y & 0xFFFFu);
         link[f] = lk;
-        nbr[f] = lk.count != 0u ? lk.nbr : kNone;
+        nbr[f] = real ? lk.nbr : kNone;
     }
 }
 
@@ -2451,6 +2545,8 @@ __global__ __launch_bounds__(256) void prepare_geometry_kernel(
                 hx[j] = float_to_half_bits(qp[0] - px);
                 hy[j] = float_to_half_bits(qp[1] - py);
                 hz[j] = float_to_half_bits(qp[2] - pz);
+            } else {
+                pad_offset(hx[0], hy[0], hz[0], (uint32_t)j, hx[j], hy[j], hz[j]);   // entry 0 of a block is a real face
             }
         }
         uint2 *g = reinterpret_cast<uint2 *>(geo + (size_t)b * 12u);
@@ -2596,7 +2692,7 @@ struct LaunchForward {
             hipMemsetAsync(p.queue, 0, sizeof(uint32_t), stream);
             hipLaunchKernelGGL((forward_persistent_kernel<DEG, HALF>), dim3(nb < resident ? nb : resident), b, 0, stream, p,
                                p.queue, nb);
-        } else if (forward_mode == 3u) {   // the reference's quotient scan (scan_faces_strict); statistics stay on the canonical scan
+        } else if (forward_mode == 3u) {   // every face divided (scan_faces_strict); statistics stay on the filtered scan
             if (bench)
                 hipLaunchKernelGGL((forward_kernel<DEG, HALF, true, false, false, kScanStrict>), g, b, 0, stream, p);
             else if (p.nq)
@@ -2864,7 +2960,6 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     p.attr_grad = static_cast<float *>(attribute_grad);
     p.point_error = static_cast<float *>(point_error);
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
-    p.strict = opts->forward_mode == 3u ? 1u : 0u;
     p.attr_pitch = opts->attr_grad_pitch ? opts->attr_grad_pitch : attribute_dim(sh_degree);
     if (p.attr_pitch < attribute_dim(sh_degree))
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: attr_grad_pitch smaller than the attribute dimension");

@@ -237,12 +237,13 @@ class Pipeline:
         #: 0 auto, 1 per-lane atomics, 2 wave pre-reduced atomics, 3 block cache, 4 direct row atomics
         #: (rf_launch_opts.backward_mode)
         self.backward_mode = 0
-        #: 0 auto, 1 face blocks requested one at a time, 2 the first six of a cell together (rf_launch_opts.forward_mode;
-        #: same results, auto picks by launch shape); 3 = the reference's own per-face quotient scan
-        #: (tracing_utils.cuh:43-67) in trace_forward, trace_backward and trace_benchmark: the reference's tie-breaking
-        #: where two exits agree to an ulp, at the price of a divide per face (``strict_reference_scan`` sets it); 4 =
-        #: experiment: persistent waves refilling dead lanes from a queue (ballot + prefix count; slower);
-        #: 5 = mode 2 behind a block-level LDS table of cell records and face blocks (auto picks it for sorted flat batches)
+        #: how the scans of a launch are scheduled (rf_launch_opts.forward_mode); every mode returns the same results bit
+        #: for bit -- the reference's scan, tracing_utils.cuh:43-67.  0 auto, 1 face blocks requested one at a time, 2 the
+        #: first six of a cell together (auto picks by launch shape); 3 = every face divided, the way the reference
+        #: writes it (the independent instance the filtered scan is tested against; ``strict_reference_scan`` sets it,
+        #: 40 % slower); 4 = experiment: persistent waves refilling dead lanes from a queue (ballot + prefix count; slower,
+        #: DESIGN.md 4.1); 5 = mode 2 behind a block-level LDS table of cell records and face blocks (auto picks it for
+        #: sorted flat batches)
         self.forward_mode = 0
         #: set by trace_backward: True when it replayed the hop trail of its trace_forward, False when it walked again
         self.last_backward_replayed = None
@@ -319,8 +320,8 @@ class Pipeline:
 
     @property
     def strict_reference_scan(self) -> bool:
-        """True: every scan divides every face and keeps a running minimum of the rounded quotients, exactly as
-        tracing_utils.cuh:43-67 writes it (forward_mode 3), instead of the divide-free canonical scan."""
+        """True: every scan divides every face and keeps a running minimum of the rounded quotients, the way
+        tracing_utils.cuh:43-67 writes it (forward_mode 3) -- same results as the default filtered scan, slower."""
         return int(self.forward_mode) == 3
 
     @strict_reference_scan.setter
@@ -522,7 +523,7 @@ class Pipeline:
     def _trail_key(self, foam, ray_keys, settings):
         """``ray_keys``: _source_key of rays, start_point and depth_quantiles."""
         return (tuple(self._tkey(t) for t in foam),) + tuple(ray_keys) + (
-            float(settings.weight_threshold), int(settings.max_intersections), int(self.forward_mode) == 3)
+            float(settings.weight_threshold), int(settings.max_intersections))
 
     def _ray_order(self, opts, rays_c, start_c, num_rays, key=None):
         """Set opts.ray_order for a flat batch: the permutation rf_build_ray_order computes, cached on

@@ -132,12 +132,12 @@ def test_live_reference_source_agrees_with_oracle(foam_factory):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src/tracing"), reason="reference sources not on this box")
-def test_canonical_arithmetic_takes_the_reference_sources_paths_on_a_large_frame():
-    """57,600 rays x ~60 cells x ~17 faces = 6e7 face tests of a 60k-point foam: how often does the canonical
-    arithmetic (explicit FMAs, the (P - O) + o/2 association, exits compared by cross-multiplication instead of by
-    rounded quotients) pick another exit face than the reference's source text compiled without any contraction?
-    Only at exact-tie scale: a handful of rays insert or skip a zero-length segment (measured: 13 rays; 7 with
-    rounded-quotient comparison, from the FMAs alone), and rgba agrees to 1e-5 everywhere."""
+def test_pinned_arithmetic_takes_the_reference_sources_paths_on_a_large_frame():
+    """57,600 rays x ~60 cells x ~17 faces = 6e7 face tests of a 60k-point foam: the oracle evaluates the reference's
+    scan (every face's rounded quotient, (P + o/2) - O) with its FMAs spelled out; how often does that pick another exit
+    face than the reference's source text compiled without any contraction?  Only at exact-tie scale, from the FMAs
+    alone: a handful of rays insert or skip a zero-length segment (measured: 7 rays), and rgba agrees to 1e-5
+    everywhere.  Against the CONTRACTED build of the same source (what nvcc's default does) fewer still."""
     from oracle import refsrc as Rf
     from radfoam_amd import foam
 
@@ -149,7 +149,7 @@ def test_canonical_arithmetic_takes_the_reference_sources_paths_on_a_large_frame
     ro = Rf.trace_forward(*args, rays, start)
     oo = O.trace_forward(*args, rays, start)
     differ = int((ro["num_intersections"] != oo["num_intersections"]).sum())
-    assert differ <= 30, differ                       # 5e-4 of the rays; observed 13
+    assert differ <= 15, differ                       # observed 7
     assert float(np.abs(ro["rgba"] - oo["rgba"]).max()) < 2e-5
     assert float(ro["rgba"][..., 3].max()) > 0.9 and float(ro["num_intersections"].mean()) > 40
 
@@ -169,7 +169,7 @@ def _envelope_case(name):
     if not cached and n > 500_000 and not os.environ.get("RF_TEST_LARGE"):
         pytest.skip(f"the {n}-point foam is not cached (Qhull takes minutes): python -m radfoam_amd.foam {n} {seed}")
     fm, d = PE.load_foam(name)
-    return PE, PE.measure(fm, d, with_quotient_mode=True)
+    return PE, PE.measure(fm, d)
 
 
 @pytest.mark.parametrize("name", ["c2", "north-star"])
@@ -177,7 +177,7 @@ def test_oracle_is_inside_the_references_own_envelope_at_baseline_scale(name):
     """every 6th row and column of the BASELINE frames (57,600 rays; 500 k points and the 2 M
     north-star foam) through the reference SOURCE compiled without and with FMA contraction, and through the oracle
     (== the HIP kernels bit for bit), forward and backward.  The bar and the reasoning are in
-    oracle/parity_envelope.py; the committed record is profiles/r03/parity_baseline_scale.json."""
+    oracle/parity_envelope.py; the committed record is profiles/r05/parity_baseline_scale.json."""
     PE, rec = _envelope_case(name)
     assert PE.check(rec) == [], rec
     own, o, of = rec["ref_fma_vs_ref"], rec["oracle_vs_ref"], rec["oracle_vs_ref_fma"]
@@ -188,12 +188,12 @@ def test_oracle_is_inside_the_references_own_envelope_at_baseline_scale(name):
     # colours: at most a couple of tie rays leave the north star's 1e-4, as between the reference's own builds
     assert max(o["rays_drgba_gt_1e-4"], of["rays_drgba_gt_1e-4"]) <= 3
     # the north star's tolerances taken literally: share of rays / of gradient elements inside them
-    for pair in (o, of, rec["oracle_quotient_scan_vs_ref"]):
+    for pair in (o, of):
         assert pair["frac_rays_within_1e-4_rgba"] >= 0.9999
         assert pair["points_grad_frac_elements_within_1e-3"] >= 0.9995 and pair["attr_grad_frac_elements_within_1e-3"] >= 0.9999
-    # the quotient scan (forward_mode 3 of the kernels) stays within 2x the reference's own distance between its builds
-    assert rec["oracle_quotient_scan_vs_ref"]["points_grad_rel_l2"] <= 2.0 * max(own["points_grad_rel_l2"], 1e-4)
+    # overall: within 2x the reference's own distance between its builds (PE.check), per frame ...
+    assert min(o["points_grad_rel_l2"], of["points_grad_rel_l2"]) <= 2.0 * max(own["points_grad_rel_l2"], 1e-4)
     _ENVELOPE_RECORDS[name] = rec
-    if len(_ENVELOPE_RECORDS) == 2:     # both frames measured in this session: the canonical scan over the two together
+    if len(_ENVELOPE_RECORDS) == 2:     # ... and not further than the reference from itself over the two frames together
         ratios, bad = PE.check_frames(list(_ENVELOPE_RECORDS.values()))
         assert bad == [], (ratios, bad)
