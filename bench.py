@@ -99,6 +99,13 @@ WORKLOADS = {
     # stand-ins for the two configs that need a dataset / trained checkpoint; labelled as such
     "train-batch": dict(points=2_000_000, seed=5, sh=3, width=0, height=0, forward_only=False, kind="batch",
                         rays=1_000_000, label="stand-in for BASELINE config 4 (training batch)"),
+    # the same batch through the foam as TRAINING sees it: the scene's density is a softplus, never exactly 0, and the
+    # reference sets empty cells to raw -1 -> 4.5e-6 > 1e-6 (scene.py:202-217,459): every segment is "lit" (fetches its
+    # colour row, emits a gradient row).  The synthetic foam's exact-zero shell (16 % lit) is the easy case.
+    "train-batch-lit": dict(points=2_000_000, seed=5, sh=3, width=0, height=0, forward_only=False, kind="batch",
+                            rays=1_000_000, empty_density=4.5e-6,
+                            label="stand-in for BASELINE config 4 (training batch, every segment lit as the scene's "
+                                  "softplus density makes it)"),
     "render": dict(points=1_000_000, seed=2, sh=3, width=1557, height=1038, forward_only=True, kind="render",
                    label="stand-in for BASELINE config 3 (benchmark.py render path)"),
     # BASELINE config 4 as a LOOP: the reference's unmodified RadFoamScene driven as train.py:162-270 drives it
@@ -142,6 +149,12 @@ def parse_args(argv=None):
                          "5 eager behind the block-level LDS cell table (auto for sorted flat batches)")
     ap.add_argument("--grad-pitch", default=None, help="Pipeline.gradient_row_pitch: auto (default), dense, or floats")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeat-frame", action="store_true",
+                    help="time the steps on ONE frame / batch traced over and over (what rounds 1-4 reported) instead of on "
+                         "rays that are new in every step; the default line reports this as detail.value_repeated_frame")
+    ap.add_argument("--no-repeated-frame", action="store_true",
+                    help="skip the extra (untimed for the metric) repeated-frame measurement: profiling runs, whose "
+                         "per-kernel averages should be those of the fresh-ray steps alone")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="default line only: skip the untimed `other_workloads` record (c2, c5, render, train-batch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
@@ -204,6 +217,12 @@ def orbit_camera(width, height, rank):
     cam["forward"] = np.array([s, 0.0, c], dtype=np.float32)
     cam["right"] = np.array([c, 0.0, -s], dtype=np.float32)
     return cam
+
+
+def view_camera(width, height, rank, view):
+    """The camera of step `view` of rank `rank`: orbit_camera(rank) moved on by 1.5 degrees per view -- a camera path, as
+    benchmark.py:95-139 renders a different test camera in every frame; view 0 is orbit_camera(rank) itself."""
+    return orbit_camera(width, height, rank + view * (1.5 / 45.0))
 
 
 def training_batch(fm, num_rays, seed):
@@ -348,7 +367,7 @@ def run_train_loop(args, W, env):
     }
 
 
-OTHER_WORKLOADS = ("c2", "c5", "render", "train-batch")
+OTHER_WORKLOADS = ("c2", "c5", "render", "train-batch", "train-batch-lit")
 
 
 def other_workloads(args, env):
@@ -366,6 +385,7 @@ def other_workloads(args, env):
                 "workload": r["config"]["workload"], "metric": r["metric"], "value": r["value"], "unit": r["unit"],
                 "steps": sub.steps, "warmup": sub.warmup, "ms_per_step": r["ms_per_step"],
                 "forward_ms": det.get("forward_ms"), "backward_ms": det.get("backward_ms"),
+                "rays": det.get("rays"), "value_repeated_frame": det.get("value_repeated_frame"),
                 "foam_pack_ms": det.get("foam_pack_ms"), "foam_csr": det.get("foam_csr"),
                 "matches_gpu_bitwise": cb.get("matches_gpu_bitwise"),
                 "points_grad_rel_l2": cb.get("points_grad_rel_l2"), "attr_grad_rel_l2": cb.get("attr_grad_rel_l2"),
@@ -416,19 +436,26 @@ def run_workload(args, W, env):
     if world > 1 and rank == 0:
         dist.barrier()
     attr_dtype = torch.float16 if W["kind"] == "render" else torch.float32
-    if args.empty_density is not None:
+    empty_density = args.empty_density if args.empty_density is not None else W.get("empty_density")
+    if empty_density is not None:
         fm = dict(fm)
         fm["attributes"] = fm["attributes"].copy()
-        fm["attributes"][:, -1] = np.maximum(fm["attributes"][:, -1], np.float32(args.empty_density))
-        W["custom"] = True
-        W["label"] += f", empty cells at density {args.empty_density:g} (every segment lit)"
-    cam = None
-    if W["kind"] == "batch":
-        rays_np, start_np = training_batch(fm, W["rays"], W["seed"] + 100)
-    else:
-        cam = orbit_camera(W["width"], W["height"], rank if (world > 1 and not strong) else 0)
-        rays_np = foam.camera_rays(cam)
-        start_np = np.full(rays_np.shape[:-1], foam.nearest_point(fm["points"], cam["position"]), dtype=np.uint32)
+        fm["attributes"][:, -1] = np.maximum(fm["attributes"][:, -1], np.float32(empty_density))
+        if args.empty_density is not None:
+            W["custom"] = True
+            W["label"] += f", empty cells at density {args.empty_density:g} (every segment lit)"
+    base_view = rank if (world > 1 and not strong) else 0
+
+    def make_view(k):
+        """Rays of view k: k = 0 is the frame / batch every untimed extra refers to; the timed steps take k = 1, 2, ..."""
+        if W["kind"] == "batch":
+            r_np, s_np = training_batch(fm, W["rays"], W["seed"] + 100 + k)
+            return None, r_np, s_np
+        c = view_camera(W["width"], W["height"], base_view, k)
+        r_np = foam.camera_rays(c)
+        return c, r_np, np.full(r_np.shape[:-1], foam.nearest_point(fm["points"], c["position"]), dtype=np.uint32)
+
+    cam, rays_np, start_np = make_view(0)
     setup_s = time.time() - t_setup
 
     points = torch.from_numpy(fm["points"]).to(dev)
@@ -478,20 +505,38 @@ def run_workload(args, W, env):
     pack_ev, fwd_ev, bwd_ev, exch_ev = [], [], [], []
     last = {}
 
-    render_out = render_cam = render_diff = render_start = None
+    render_out = render_diff = None
     if W["kind"] == "render":
         render_diff = pipe.build_adjacent_diff(points, adjacency, offsets)
         render_out = torch.zeros((W["height"], W["width"]), dtype=torch.uint32, device=dev)
-        render_cam = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
-        render_start = start.reshape(-1)[:1].contiguous()
 
-    def step(record):
+    def device_view(c, r_dev, s_dev):
+        v = {"rays": r_dev, "start": s_dev}
+        if W["kind"] == "render":
+            v["cam"] = {k: (torch.from_numpy(x) if isinstance(x, np.ndarray) else x) for k, x in c.items()}
+            v["cam_start"] = s_dev.reshape(-1)[:1].contiguous()
+        return v
+
+    view0 = device_view(cam, rays, start)
+    # The timed steps trace rays that are NEW in every step -- a camera path for frames and renders (benchmark.py:95-139
+    # renders a different test camera per frame), another shuffled batch per step for flat batches (train.py:61) -- so
+    # that nothing the pipeline learns from a trace (block order of the forward, ray order, hop trail) is learnt on the
+    # very rays it is then timed on; what a backward takes from ITS forward it may keep.  All views resident before timing.
+    fresh = []
+    if not args.repeat_frame:
+        for k in range(1, min(args.warmup + args.steps, 24) + 1):
+            c, r_np, s_np = make_view(k)
+            fresh.append(device_view(c, torch.from_numpy(r_np).to(dev), torch.from_numpy(s_np).to(dev)))
+    view_of_step = (lambda i: fresh[i % len(fresh)]) if fresh else (lambda i: view0)
+
+    def step(record, view):
+        rays, start = view["rays"], view["start"]
         if W["kind"] == "render":
             # benchmark.py's loop: the foam is static, the packed tables are cached after the first frame
             e0, e1 = ev(), ev()
             if record:
                 e0.record()
-            pipe.trace_benchmark(points, attributes, adjacency, offsets, render_diff, render_cam, render_start,
+            pipe.trace_benchmark(points, attributes, adjacency, offsets, render_diff, view["cam"], view["cam_start"],
                                  render_out, weight_threshold=0.05)
             if record:
                 e1.record()
@@ -547,7 +592,7 @@ def run_workload(args, W, env):
     # ---- warm-up (untimed); the first warm-up step also measures the rows' cost for the row cut ----
     bounds = None
     for i in range(args.warmup):
-        step(False)
+        step(False, view_of_step(i))
         sync()   # lets the pipeline see the longest ray of the batch before the next step sizes its hop trail
         if i == 0 and strong and W["kind"] == "image" and not args.no_rebalance:
             bounds = tracer.rebalance(last["out"]["num_intersections"], rays.shape[0])
@@ -556,8 +601,8 @@ def run_workload(args, W, env):
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        step(True, view_of_step(args.warmup + i))
     sync()
     if world > 1:
         dist.barrier()
@@ -579,6 +624,28 @@ def run_workload(args, W, env):
         dist.all_gather(allr, mine)
         rank_ms = [[round(float(x), 4) for x in r.tolist()] for r in allr]
 
+    # ---- the same steps on ONE frame / batch traced over and over (untimed for the metric): what rounds 1-4 reported as
+    # the value.  A repeated frame takes its forward's block order from its own previous trace.  Also leaves view 0's
+    # outputs in `last` for the extras and checks below.
+    repeated = None
+    if fresh and on_gpu and not args.no_repeated_frame:
+        timed_fwd, timed_bwd, timed_pack = list(fwd_ev), list(bwd_ev), list(pack_ev)
+        del fwd_ev[:], bwd_ev[:], pack_ev[:], exch_ev[:]
+        for _ in range(2):
+            step(False, view0)
+            sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True, view0)
+        sync()
+        rep = (time.perf_counter() - t1) / args.steps
+        repeated = {"ms_per_step": round(rep * 1e3, 4), "forward_ms": round(mean_ms(fwd_ev), 4),
+                    "backward_ms": round(mean_ms(bwd_ev), 4)}
+        fwd_ev[:], bwd_ev[:], pack_ev[:] = timed_fwd, timed_bwd, timed_pack
+    elif fresh:
+        step(False, view0)
+        sync()
+
     local_rays = (last["out"]["rgba"].numel() // 4) if last.get("out") is not None else frame_rays
     total_rays = frame_rays if (strong or world == 1) else frame_rays * world
     ms_per_step = elapsed / args.steps * 1e3
@@ -588,7 +655,22 @@ def run_workload(args, W, env):
     detail = {"forward_ms": round(fwd_ms, 4), "backward_ms": round(bwd_ms, 4), "foam_pack_ms": round(pack_ms, 4),
               "setup_seconds": round(setup_s, 1), "foam_csr": fm["csr_source"]}
     # the scheduling of the launches' blocks, learnt in the warm-up steps from the step counts of the walk itself
-    detail["tile_order"] = getattr(pipe, "tile_order_mode", None) or "static"
+    mode_name = getattr(pipe, "tile_order_mode", None) or "static"
+    if mode_name == "auto":
+        detail["tile_order"] = ("repeated frame: forward / render launches take the block order learnt on the previous trace "
+                                "of the same rays, the backward the one its forward learnt" if not fresh else
+                                "rays new in every step: forward / render launches run under the static dealing of tiles, "
+                                "the backward under the order its own forward learnt (cheapest tiles last)")
+    else:
+        detail["tile_order"] = mode_name
+    detail["rays"] = "one frame / batch traced over and over (--repeat-frame)" if not fresh else \
+        f"new in every step ({len(fresh)} views resident: " + \
+        ("a shuffled batch per step" if W["kind"] == "batch" else "a camera path, 1.5 degrees per step") + ")"
+    if repeated is not None:
+        total = frame_rays if (strong or world == 1) else frame_rays * world
+        repeated["value"] = round(total / (repeated["ms_per_step"] * 1e-3) / 1e6, 3)
+        detail["value_repeated_frame"] = repeated["value"]
+        detail["repeated_frame"] = repeated
     detail.update(tri_ms)
     if world > 1:
         detail["exchange_ms"] = round(exch_ms, 4)
@@ -856,7 +938,7 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
     from tests.helpers import grad_close
 
     sh_degree = W["sh"]
-    cores = int(O.lib().rfo_max_threads())   # OpenMP threads the oracle runs on (<= os.cpu_count())
+    cores = len(os.sched_getaffinity(0))      # every logical core this process may run on: one OpenMP thread each
     image = W["kind"] == "image"
     diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"], pad=32)
     foam_args = (sh_degree, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
@@ -875,14 +957,17 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
 
     def run(stride):
         r, s, g, sl, q, dg = sample(stride)
-        t0 = time.perf_counter()
-        f = O.trace_forward(*foam_args, r, s, depth_quantiles=q, diff=diff)
-        t1 = time.perf_counter()
-        b = None
-        if not W["forward_only"]:
-            b = O.trace_backward(*foam_args, r, s, f["rgba"], g, depth_quantiles=q, depth_indices=f.get("depth_indices"),
-                                 depth_grad_in=dg, diff=diff)
-        t2 = time.perf_counter()
+        # the scan evaluated the way the kernels evaluate it (tournament on products + certificate + dividing fallback:
+        # the same function as the reference's evaluation, tests/test_oracle.py, and twice as fast on these cores)
+        with O.scan_mode("filtered"):
+            t0 = time.perf_counter()
+            f = O.trace_forward(*foam_args, r, s, depth_quantiles=q, diff=diff, num_threads=cores)
+            t1 = time.perf_counter()
+            b = None
+            if not W["forward_only"]:
+                b = O.trace_backward(*foam_args, r, s, f["rgba"], g, depth_quantiles=q,
+                                     depth_indices=f.get("depth_indices"), depth_grad_in=dg, diff=diff, num_threads=cores)
+            t2 = time.perf_counter()
         return r.size // 6, t1 - t0, t2 - t1, f, b, (r, s, g, sl, q, dg)
 
     stride = 24
@@ -910,10 +995,10 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
         "cores": cores,
         "kind": "port",
         "sample": (f"every {stride}th row and column of the same frame" if image else f"every {stride * stride}th ray of the same batch")
-                  + f" ({n} rays = {100.0 * n / total:.1f}% of the step), oracle/rf_oracle.c with OpenMP on {cores} threads of "
-                    f"{os.cpu_count()} logical cores (rays split statically over the threads, gradients summed with "
-                    f"'omp atomic' into shared buffers -- not the thread-local buffers BASELINE.md planned, so the "
-                    f"backward understates what these cores could do); forward {tf:.2f}s"
+                  + f" ({n} rays = {100.0 * n / total:.1f}% of the step), oracle/rf_oracle.c with OpenMP on {cores} threads "
+                    f"(every logical core this process may use; the box has {os.cpu_count()}), rays dealt to the threads in "
+                    f"chunks of 64, gradients summed in thread-local write-combining tables merged at the end (no atomic "
+                    f"in the walk, BASELINE.md section 3), the scan evaluated as the kernels evaluate it; forward {tf:.2f}s"
                   + ("" if b is None else f" + backward {tb:.2f}s") + "; fp16 face table prebuilt (excluded)",
         "matches_gpu_bitwise": same,
     }
@@ -949,14 +1034,15 @@ def cpu_baseline_render(W, fm, cam, start_np, render_out, strict_scan=False):
     make_rgba8) on the SAME camera, whole frame, all host cores; its RGBA8 words against the frame the GPU just wrote."""
     from oracle import oracle as O
 
-    cores = int(O.lib().rfo_max_threads())
+    cores = len(os.sched_getaffinity(0))
     half_attrs = fm["attributes"].astype(np.float16)     # what benchmark.py feeds the fp16 pipeline (benchmark.py:36)
     diff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"])
     start = np.uint32(np.asarray(start_np).reshape(-1)[0])
-    t0 = time.perf_counter()
-    ref = O.trace_benchmark(W["sh"], fm["points"], half_attrs, fm["point_adjacency"], fm["point_adjacency_offsets"],
-                            diff, cam, start, weight_threshold=0.05)
-    dt = time.perf_counter() - t0
+    with O.scan_mode("filtered"):
+        t0 = time.perf_counter()
+        ref = O.trace_benchmark(W["sh"], fm["points"], half_attrs, fm["point_adjacency"], fm["point_adjacency_offsets"],
+                                diff, cam, start, weight_threshold=0.05, num_threads=cores)
+        dt = time.perf_counter() - t0
     got = render_out.cpu().numpy().view(np.uint32).reshape(ref.shape)
     n = int(ref.size)
     differ = int((got != ref).sum())
@@ -978,7 +1064,7 @@ def reference_source_envelope(W, fm):
     output of this run equals bit for bit (matches_gpu_bitwise) --, forward and backward: rays on another path, rays
     beyond 1e-4 / 1e-5 in rgba, gradient distances overall / on same-path rays / carried by the flipped rays, the oracle
     against both builds next to the reference against itself (oracle/parity_envelope.py has the reasoning and the bar;
-    profiles/r03/parity_baseline_scale.json the committed record)."""
+    profiles/r05/parity_baseline_scale.json the committed record)."""
     if W["kind"] != "image" or W.get("custom") or W.get("nq") or W["name"] not in ("north-star", "c2"):
         return None
     from oracle import parity_envelope as PE
@@ -986,7 +1072,7 @@ def reference_source_envelope(W, fm):
 
     if not (os.path.exists(Rf.LIB_PATH) and os.path.exists(Rf.LIB_PATH_FMA)):
         return None
-    rec = PE.measure(fm, W["sh"], width=W["width"], height=W["height"], stride=6, with_quotient_mode=False)
+    rec = PE.measure(fm, W["sh"], width=W["width"], height=W["height"], stride=6)
     rec["violations_of_the_bar"] = PE.check(rec)
     return rec
 

@@ -375,6 +375,14 @@ int rf_compact_grad_rows(const float *points_grad, const float *attr_grad, uint3
 int rf_scatter_grad_rows(const float *packed, uint32_t num_rows, uint32_t num_points, uint32_t attr_dim,
                          int mode, float *points_grad, float *attr_grad, void *stream);
 
+/* The same two with attr_grad rows `attr_pitch` floats apart (>= attr_dim): what rf_trace_backward writes when
+ * rf_launch_opts.attr_grad_pitch pads the rows to 64-byte lines.  The packed rows are the same either way. */
+int rf_compact_grad_rows_pitched(const float *points_grad, const float *attr_grad, uint32_t num_points,
+                                 uint32_t attr_dim, uint32_t attr_pitch, uint32_t capacity, uint32_t *count, float *packed,
+                                 void *stream);
+int rf_scatter_grad_rows_pitched(const float *packed, uint32_t num_rows, uint32_t num_points, uint32_t attr_dim,
+                                 uint32_t attr_pitch, int mode, float *points_grad, float *attr_grad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

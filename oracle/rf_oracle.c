@@ -204,6 +204,81 @@ static float rf_logf(float x) {
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* Thread-local write-combining table of gradient rows (rfo_trace_backward with several threads): open addressing keyed
+ * by cell, a row = [points_grad 3 | attr_grad A | point_error 1] floats.  A thread sums its rays' contributions here
+ * without any atomic and merges the table into the shared output arrays when it is 5/8 full and when its rays are done
+ * (a dense copy of the outputs per thread would be threads x N x (4 + A) floats -- 64 GB for 256
+ * threads on the 2 M-point foam). */
+typedef struct {
+    uint32_t *keys;      /* cap entries; RFO_NONE = empty */
+    float *rows;         /* cap x width */
+    uint32_t cap, used, width;
+    int A;
+    float *pg, *ag, *pe; /* the shared outputs the table is merged into (pe may be NULL) */
+} rfo_wc_t;
+
+static void rfo_wc_init(rfo_wc_t *t, uint32_t cap, int A, float *pg, float *ag, float *pe) {
+    t->cap = cap;
+    t->used = 0;
+    t->width = (uint32_t)A + 4u;
+    t->A = A;
+    t->pg = pg;
+    t->ag = ag;
+    t->pe = pe;
+    t->keys = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    t->rows = (float *)calloc((size_t)cap * t->width, sizeof(float));
+    memset(t->keys, 0xFF, sizeof(uint32_t) * cap);
+}
+
+static void rfo_wc_flush(rfo_wc_t *t) {
+    for (uint32_t e = 0; e < t->cap; ++e) {
+        const uint32_t cell = t->keys[e];
+        if (cell == RFO_NONE) continue;
+        float *row = t->rows + (size_t)e * t->width;
+        for (int i = 0; i < 3; ++i)
+            if (row[i] != 0.0f) {
+#pragma omp atomic
+                t->pg[3 * (size_t)cell + i] += row[i];
+            }
+        for (int i = 0; i < t->A; ++i)
+            if (row[3 + i] != 0.0f) {
+#pragma omp atomic
+                t->ag[(size_t)cell * t->A + i] += row[3 + i];
+            }
+        if (t->pe && row[3 + t->A] != 0.0f) {
+#pragma omp atomic
+            t->pe[cell] += row[3 + t->A];
+        }
+        memset(row, 0, sizeof(float) * t->width);
+        t->keys[e] = RFO_NONE;
+    }
+    t->used = 0;
+}
+
+static inline float *rfo_wc_row(rfo_wc_t *t, uint32_t cell) {
+    const uint32_t mask = t->cap - 1u;
+    uint32_t e = (cell * 2654435761u) >> 7 & mask;
+    for (;;) {
+        const uint32_t k = t->keys[e];
+        if (k == cell) return t->rows + (size_t)e * t->width;
+        if (k == RFO_NONE) break;
+        e = (e + 1u) & mask;
+    }
+    if (t->used * 8u >= t->cap * 5u) {      /* merge, then insert into the empty table */
+        rfo_wc_flush(t);
+        e = (cell * 2654435761u) >> 7 & mask;
+    }
+    t->keys[e] = cell;
+    t->used++;
+    return t->rows + (size_t)e * t->width;
+}
+
+static void rfo_wc_free(rfo_wc_t *t) {
+    free(t->keys);
+    free(t->rows);
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* float32 canonical instance                                                            */
 
 #define REAL float
@@ -274,8 +349,9 @@ void rfo_build_adjacent_diff(const float *points, uint32_t num_points, const uin
 
 static int pick_threads(int num_threads) {
 #ifdef _OPENMP
-    int m = omp_get_max_threads();
-    if (num_threads <= 0 || num_threads > m) num_threads = m;
+    /* 0: OpenMP's default; otherwise what the caller asks for (bench.py: one thread per logical core it may run on) */
+    if (num_threads <= 0) num_threads = omp_get_max_threads();
+    if (num_threads > 1024) num_threads = 1024;
     return num_threads;
 #else
     (void)num_threads;
@@ -421,20 +497,33 @@ void rfo_trace_backward(int sh_degree, int attr_half, rfo_settings settings, uin
     const float *err_p = ray_error ? (attr_half ? err_f : (const float *)ray_error) : NULL;
 
     int nt = pick_threads(num_threads);
-    /* ONE set of fp32 accumulators shared by all threads (omp atomic): what a many-core CPU
-     * implementation would do; per-thread copies cost nt*N*(4+A) floats to zero and reduce */
+    /* fp32 accumulators of the outputs; with several threads every thread sums in its own write-combining table
+     * (rfo_wc_t) and merges it into these -- no atomic in the walk */
     size_t per = (size_t)num_points * (3 + A + 1);
     float *tl = (float *)calloc(per ? per : 1, sizeof(float));
     float *pg = tl;
     float *ag = pg + (size_t)num_points * 3;
     float *pe = ag + (size_t)num_points * A;
-#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
-    for (int64_t r = 0; r < (int64_t)num_rays; ++r) {
-        backward_ray_f32(&fm, rays + 6 * r, start[r], nq,
-                         quantiles ? quantiles + (size_t)r * nq : NULL,
-                         qidx ? qidx + (size_t)r * nq : NULL, rgba_p + 4 * r, g_p + 4 * r,
-                         depth_grad ? depth_grad + (size_t)r * nq : NULL,
-                         err_p ? err_p + r : NULL, pg, ag, point_error ? pe : NULL, strict, nt > 1);
+#pragma omp parallel num_threads(nt)
+    {
+        rfo_wc_t table;
+        sink_t_f32 sink = {pg, ag, point_error ? pe : NULL, 0, NULL};
+        if (nt > 1) {
+            rfo_wc_init(&table, 1u << 15, A, pg, ag, point_error ? pe : NULL);
+            sink.wc = &table;
+        }
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t r = 0; r < (int64_t)num_rays; ++r) {
+            backward_ray_f32(&fm, rays + 6 * r, start[r], nq,
+                             quantiles ? quantiles + (size_t)r * nq : NULL,
+                             qidx ? qidx + (size_t)r * nq : NULL, rgba_p + 4 * r, g_p + 4 * r,
+                             depth_grad ? depth_grad + (size_t)r * nq : NULL,
+                             err_p ? err_p + r : NULL, &sink, strict);
+        }
+        if (nt > 1) {
+            rfo_wc_flush(&table);
+            rfo_wc_free(&table);
+        }
     }
     memcpy(points_grad, pg, sizeof(float) * 3 * (size_t)num_points);
     for (size_t i = 0; i < (size_t)num_points * A; ++i) store_attr(attr_grad, i, ag[i], attr_half);
@@ -580,13 +669,13 @@ void rfo_trace_backward_f64(int sh_degree, rfo_settings settings, uint32_t num_p
     memset(points_grad, 0, sizeof(double) * 3 * (size_t)num_points);
     memset(attr_grad, 0, sizeof(double) * (size_t)A * num_points);
     if (point_error) memset(point_error, 0, sizeof(double) * (size_t)num_points);
+    sink_t_f64 sink = {points_grad, attr_grad, point_error, 0, NULL};
     for (uint32_t r = 0; r < num_rays; ++r) {
         backward_ray_f64(&fm, rays + 6 * (size_t)r, start[r], nq,
                          quantiles ? quantiles + (size_t)r * nq : NULL,
                          qidx ? qidx + (size_t)r * nq : NULL, rgba + 4 * (size_t)r,
                          rgba_grad + 4 * (size_t)r,
                          depth_grad ? depth_grad + (size_t)r * nq : NULL,
-                         ray_error ? ray_error + r : NULL, points_grad, attr_grad, point_error,
-                         strict, 0);
+                         ray_error ? ray_error + r : NULL, &sink, strict);
     }
 }

@@ -103,6 +103,8 @@ SYMBOLS = {
     "rf_grad_row_pitch": (_U32, [_U32]),
     "rf_compact_grad_rows": (_INT, [_P, _P, _U32, _U32, _U32, _P, _P, _P]),
     "rf_scatter_grad_rows": (_INT, [_P, _U32, _U32, _U32, _INT, _P, _P, _P]),
+    "rf_compact_grad_rows_pitched": (_INT, [_P, _P, _U32, _U32, _U32, _U32, _P, _P, _P]),
+    "rf_scatter_grad_rows_pitched": (_INT, [_P, _U32, _U32, _U32, _U32, _INT, _P, _P, _P]),
     "rf_trace_benchmark": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _P,
                                   C.POINTER(Camera), _P, _P, C.POINTER(LaunchOpts), _P]),
 }

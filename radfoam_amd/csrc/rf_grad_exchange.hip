@@ -25,7 +25,8 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void compact_grad_rows_kernel(const float *__restrict__ points_grad,
                                                                 const float *__restrict__ attr_grad,
                                                                 uint32_t num_points, uint32_t attr_dim,
-                                                                uint32_t capacity, uint32_t *__restrict__ count,
+                                                                uint32_t attr_pitch, uint32_t capacity,
+                                                                uint32_t *__restrict__ count,
                                                                 float *__restrict__ packed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void compact_grad_rows_kernel(const float *__r
     bool any = false;
     if (i < num_points) {
         const float *pg = points_grad + 3 * (size_t)i;
-        const float *ag = attr_grad + (size_t)i * attr_dim;
+        const float *ag = attr_grad + (size_t)i * attr_pitch;
         uint32_t acc = __builtin_bit_cast(uint32_t, pg[0]) | __builtin_bit_cast(uint32_t, pg[1]) |
                        __builtin_bit_cast(uint32_t, pg[2]);
         if constexpr (VEC4) {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void compact_grad_rows_kernel(const float *__r
     if (slot >= capacity) return;
     float *dst = packed + (size_t)slot * pitch;
     const float *pg = points_grad + 3 * (size_t)i;
-    const float *ag = attr_grad + (size_t)i * attr_dim;
+    const float *ag = attr_grad + (size_t)i * attr_pitch;
     dst[0] = __builtin_bit_cast(float, i);
     dst[1] = pg[0];
     dst[2] = pg[1];
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void compact_grad_rows_kernel(const float *__r
 template <int MODE>
 __global__ __launch_bounds__(256) void scatter_grad_rows_kernel(const float *__restrict__ packed, uint32_t num_rows,
                                                                 uint32_t num_points, uint32_t attr_dim,
+                                                                uint32_t attr_pitch,
                                                                 float *__restrict__ points_grad,
                                                                 float *__restrict__ attr_grad) {
     const uint32_t pitch = grad_row_pitch(attr_dim);
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void scatter_grad_rows_kernel(const float *__r
     if (col == 0u || col >= 4u + attr_dim) return;
     const uint32_t cell = __builtin_bit_cast(uint32_t, packed[(size_t)row * pitch]);
     if (cell >= num_points) return;
-    float *dst = col < 4u ? points_grad + 3 * (size_t)cell + (col - 1u) : attr_grad + (size_t)cell * attr_dim + (col - 4u);
+    float *dst = col < 4u ? points_grad + 3 * (size_t)cell + (col - 1u) : attr_grad + (size_t)cell * attr_pitch + (col - 4u);
     if constexpr (MODE == 0) {
         const float v = packed[idx];
         if (v != 0.0f) *dst = *dst + v;
@@ -103,42 +105,57 @@ extern "C" {
 
 uint32_t rf_grad_row_pitch(uint32_t attr_dim) { return grad_row_pitch(attr_dim); }
 
-int rf_compact_grad_rows(const float *points_grad, const float *attr_grad, uint32_t num_points,
-                         uint32_t attr_dim, uint32_t capacity, uint32_t *count, float *packed, void *stream) {
+int rf_compact_grad_rows_pitched(const float *points_grad, const float *attr_grad, uint32_t num_points,
+                                 uint32_t attr_dim, uint32_t attr_pitch, uint32_t capacity, uint32_t *count, float *packed,
+                                 void *stream) {
     g_err[0] = 0;
     if (num_points == 0) return RF_OK;
     if (!points_grad || !attr_grad || !count || (capacity && !packed) || attr_dim == 0)
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_compact_grad_rows: null pointer");
+    if (attr_pitch < attr_dim) return fail(RF_ERR_INVALID_ARGUMENT, "rf_compact_grad_rows: attr_pitch below attr_dim");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((num_points + 255u) / 256u), block(256);
     // rows readable as 16-byte vectors iff the row pitch and the base keep them aligned
-    const bool vec4 = (attr_dim % 4u) == 0u && (reinterpret_cast<uintptr_t>(attr_grad) % 16u) == 0u;
+    const bool vec4 = (attr_dim % 4u) == 0u && (attr_pitch % 4u) == 0u && (reinterpret_cast<uintptr_t>(attr_grad) % 16u) == 0u;
     if (vec4)
         hipLaunchKernelGGL(compact_grad_rows_kernel<true>, grid, block, 0, s, points_grad, attr_grad, num_points,
-                           attr_dim, capacity, count, packed);
+                           attr_dim, attr_pitch, capacity, count, packed);
     else
         hipLaunchKernelGGL(compact_grad_rows_kernel<false>, grid, block, 0, s, points_grad, attr_grad, num_points,
-                           attr_dim, capacity, count, packed);
+                           attr_dim, attr_pitch, capacity, count, packed);
     return check_launch("rf_compact_grad_rows");
 }
 
-int rf_scatter_grad_rows(const float *packed, uint32_t num_rows, uint32_t num_points, uint32_t attr_dim,
-                         int mode, float *points_grad, float *attr_grad, void *stream) {
+int rf_compact_grad_rows(const float *points_grad, const float *attr_grad, uint32_t num_points,
+                         uint32_t attr_dim, uint32_t capacity, uint32_t *count, float *packed, void *stream) {
+    return rf_compact_grad_rows_pitched(points_grad, attr_grad, num_points, attr_dim, attr_dim, capacity, count, packed,
+                                        stream);
+}
+
+int rf_scatter_grad_rows_pitched(const float *packed, uint32_t num_rows, uint32_t num_points, uint32_t attr_dim,
+                                 uint32_t attr_pitch, int mode, float *points_grad, float *attr_grad, void *stream) {
     g_err[0] = 0;
     if (num_rows == 0) return RF_OK;
     if (!packed || !points_grad || !attr_grad || attr_dim == 0)
         return fail(RF_ERR_INVALID_ARGUMENT, "rf_scatter_grad_rows: null pointer");
+    if (attr_pitch < attr_dim) return fail(RF_ERR_INVALID_ARGUMENT, "rf_scatter_grad_rows: attr_pitch below attr_dim");
     if (mode != 0 && mode != 1) return fail(RF_ERR_INVALID_ARGUMENT, "rf_scatter_grad_rows: mode must be 0 or 1");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t total = (size_t)num_rows * grad_row_pitch(attr_dim);
     const dim3 grid((unsigned)((total + 255u) / 256u)), block(256);
     if (mode == 0)
         hipLaunchKernelGGL(scatter_grad_rows_kernel<0>, grid, block, 0, s, packed, num_rows, num_points, attr_dim,
-                           points_grad, attr_grad);
+                           attr_pitch, points_grad, attr_grad);
     else
         hipLaunchKernelGGL(scatter_grad_rows_kernel<1>, grid, block, 0, s, packed, num_rows, num_points, attr_dim,
-                           points_grad, attr_grad);
+                           attr_pitch, points_grad, attr_grad);
     return check_launch("rf_scatter_grad_rows");
+}
+
+int rf_scatter_grad_rows(const float *packed, uint32_t num_rows, uint32_t num_points, uint32_t attr_dim,
+                         int mode, float *points_grad, float *attr_grad, void *stream) {
+    return rf_scatter_grad_rows_pitched(packed, num_rows, num_points, attr_dim, attr_dim, mode, points_grad, attr_grad,
+                                        stream);
 }
 
 }  // extern "C"

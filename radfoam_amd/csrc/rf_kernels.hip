@@ -848,8 +848,11 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
             }
             if (sr.k == kNone) alive = false;
         }
-        uint32_t nxt = 0, nnb = 0, ncnt = 0;
-        float4 nhead = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // What compositing needs of the cell being left; the hop then loads the next cell straight into the walk's state
+        // (cur, head, nb, cnt) -- with the old values dead, the exec-masked loads land in those very registers instead of
+        // in temporaries that have to be copied over at the end of the step (seven moves per lane-step before).
+        const float dens = head.w;
+        const uint32_t cell = cur;
         if constexpr (CACHED) {
             // everything requested so far has been consumed by the scan (or belongs to lanes that are done): telling the
             // compiler so keeps its wait for the table's stores below from covering the link load as well
@@ -857,53 +860,53 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
             Link link{0u, 0u, 0u};
             if (alive) link = fv.link[nb + sr.k];
             // while the link is on its way: what this cell's scan fetched from memory goes into the table
-            if (scanned && fetched) cache_fill(cache, kEntries, cur, head, GB);
+            if (scanned && fetched) cache_fill(cache, kEntries, cell, head, GB);
             if (alive) {
-                nxt = link.nbr;
-                nnb = link.first;
-                ncnt = link.count;
-                fetched = !cache_read(cache, kEntries, nxt, nhead, GB);
+                cur = link.nbr;
+                nb = link.first;
+                cnt = link.count;
+                fetched = !cache_read(cache, kEntries, cur, head, GB);
                 if (fetched) {
-                    nhead = fv.cells[nxt];
-                    load_geo_blocks(fv.geo, nnb, ncnt, GB);
+                    head = fv.cells[cur];
+                    load_geo_blocks(fv.geo, nb, cnt, GB);
                 }
             }
         }
         if (alive) {
             if constexpr (!CACHED) {
                 const Link link = fv.link[nb + sr.k];
-                nxt = link.nbr;
-                nnb = link.first;
-                ncnt = link.count;
-                nhead = fv.cells[nxt];
-                if constexpr (EAGER) load_geo_blocks(fv.geo, nnb, ncnt, GB);
+                cur = link.nbr;
+                nb = link.first;
+                cnt = link.count;
+                head = fv.cells[cur];
+                if constexpr (EAGER) load_geo_blocks(fv.geo, nb, cnt, GB);
             }
             if constexpr (!BENCH) {
                 // trail: the cell each hop enters, for trace_backward to replay
                 if (p.trail) {
-                    if (hops < p.trail_cap) p.trail[(size_t)hops * p.trail_slots + slot] = nxt;
+                    if (hops < p.trail_cap) p.trail[(size_t)hops * p.trail_slots + slot] = cur;
                     hops++;
                 }
             }
         }
         if (alive) {
             const float t1 = sr.t1;
+            const bool segment = t1 > t0;
             if (want_stats) st_hops++;
-            if (want_stats && t1 > t0) {
+            if (want_stats && segment) {
                 st_seg++;
-                st_lit += (head.w > 1e-6f) ? 1u : 0u;
+                st_lit += (dens > 1e-6f) ? 1u : 0u;
             }
             // A segment through a cell of density exactly 0 changes nothing (alpha = 1 - exp(-0) = 0,
             // weight 0, transmittance unchanged): skipped -- a wave in empty space skips the block.
-            if (t1 > t0 && head.w != 0.0f) {
-                float s = head.w;
+            if (segment && dens != 0.0f) {
                 float r = 0.0f, g = 0.0f, b = 0.0f;
-                if (s > 1e-6f) cell_rgb<DEG, HALF>(fv, cur, sh, r, g, b);
+                if (dens > 1e-6f) cell_rgb<DEG, HALF>(fv, cell, sh, r, g, b);
                 float dt = __builtin_fmaxf(t1 - t0, 0.0f);
-                float alpha = 1.0f - exp_(-s * dt);
+                float alpha = 1.0f - exp_(-dens * dt);
                 float w = T * alpha;
                 if constexpr (!BENCH) {
-                    if (p.contribution) unsafeAtomicAdd(p.contribution + cur, w);
+                    if (p.contribution) unsafeAtomicAdd(p.contribution + cell, w);
                 }
                 Cr = fma_(w, r, Cr);
                 Cg = fma_(w, g, Cg);
@@ -911,8 +914,8 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
                 float Tn = T * (1.0f - alpha);
                 if constexpr (QUANT) {
                     while (qi < nq && Tn < cq) {
-                        p.qdepth[(size_t)ray * nq + qi] = t0 + log_(T / cq) / s;
-                        p.qidx[(size_t)ray * nq + qi] = cur;
+                        p.qdepth[(size_t)ray * nq + qi] = t0 + log_(T / cq) / dens;
+                        p.qidx[(size_t)ray * nq + qi] = cell;
                         qi++;
                         if (qi < nq) cq = qp[qi];
                     }
@@ -920,11 +923,7 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
                 T = Tn;
                 if (!(T > thr)) alive = false;
             }
-            t0 = __builtin_fmaxf(t0, t1);
-            cur = nxt;
-            head = nhead;
-            nb = nnb;
-            cnt = ncnt;
+            t0 = segment ? t1 : t0;     // fmaxf(t0, t1): t0 is never NaN
         }
     }
 

@@ -184,18 +184,26 @@ class SparseGradExchange:
     def _pitch(a: int) -> int:
         return (1 + 3 + a + 3) // 4 * 4
 
+    @staticmethod
+    def _row_pitch(attr_grad) -> int:
+        """Floats between two rows of ``attr_grad``: A for the reference's dense [N, A], 16 / 32 / 64 for the [N, A] view
+        of rows on 64-byte lines that Pipeline.trace_backward returns by default (gradient_row_pitch "auto")."""
+        n, a = attr_grad.shape
+        if attr_grad.stride(1) != 1 or (n > 1 and attr_grad.stride(0) < a):
+            raise RuntimeError("SparseGradExchange needs attr_grad rows of contiguous floats (a [N, A] tensor or a "
+                               "[N, A] view of padded rows), got strides %r" % (tuple(attr_grad.stride()),))
+        return int(attr_grad.stride(0)) if n > 1 else a
+
     def _compact(self, points_grad, attr_grad, send, count):
         n, a = attr_grad.shape
-        if not attr_grad.is_contiguous():
-            raise RuntimeError("SparseGradExchange needs the dense [N, A] gradient rows: set "
-                               "pipeline.gradient_row_pitch = 'dense' (ShardedTracer does)")
+        pitch = self._row_pitch(attr_grad)
         if points_grad.is_cuda:
             from . import _lib
             lib = _lib.load()
             with torch.cuda.device(points_grad.device):
-                rc = lib.rf_compact_grad_rows(points_grad.data_ptr(), attr_grad.data_ptr(), n, a, send.shape[0],
-                                              count.data_ptr(), send.data_ptr(),
-                                              torch.cuda.current_stream(points_grad.device).cuda_stream)
+                rc = lib.rf_compact_grad_rows_pitched(points_grad.data_ptr(), attr_grad.data_ptr(), n, a, pitch,
+                                                      send.shape[0], count.data_ptr(), send.data_ptr(),
+                                                      torch.cuda.current_stream(points_grad.device).cuda_stream)
             _lib.check(rc)
             return
         touched = ((points_grad != 0).any(dim=1) | (attr_grad != 0).any(dim=1)).nonzero().reshape(-1)
@@ -208,8 +216,8 @@ class SparseGradExchange:
         send[:k, 4:4 + a] = attr_grad[idx]
         send[:k, 4 + a:] = 0
 
-    @staticmethod
-    def _scatter(rows, k, points_grad, attr_grad, zero):
+    @classmethod
+    def _scatter(cls, rows, k, points_grad, attr_grad, zero):
         if k == 0:
             return
         n, a = attr_grad.shape
@@ -217,9 +225,9 @@ class SparseGradExchange:
             from . import _lib
             lib = _lib.load()
             with torch.cuda.device(points_grad.device):
-                rc = lib.rf_scatter_grad_rows(rows.data_ptr(), k, n, a, 1 if zero else 0, points_grad.data_ptr(),
-                                              attr_grad.data_ptr(),
-                                              torch.cuda.current_stream(points_grad.device).cuda_stream)
+                rc = lib.rf_scatter_grad_rows_pitched(rows.data_ptr(), k, n, a, cls._row_pitch(attr_grad),
+                                                      1 if zero else 0, points_grad.data_ptr(), attr_grad.data_ptr(),
+                                                      torch.cuda.current_stream(points_grad.device).cuda_stream)
             _lib.check(rc)
             return
         idx = rows[:k, 0].contiguous().view(torch.int32).to(torch.int64)
@@ -243,8 +251,13 @@ class SparseGradExchange:
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         pg, ag = backward_result["points_grad"], backward_result["attr_grad"]
         flat = backward_result.get("flat_grad")
-        if flat is None or ag.dtype != torch.float32 or ag.data_ptr() != flat.data_ptr() + pg.numel() * 4:
-            all_reduce_gradients(backward_result, group=self.group)     # fp16 pipelines: converted attr_grad
+        # the rows must be the fp32 accumulator itself (a view into flat_grad, whatever its row pitch), not a converted
+        # copy: fp16 pipelines return a half attr_grad next to the fp32 flat buffer
+        inside = flat is not None and ag.dtype == torch.float32 and pg.dtype == torch.float32 and \
+            ag.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() and \
+            pg.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() and ag.dim() == 2 and ag.stride(1) == 1
+        if not inside:
+            all_reduce_gradients(backward_result, group=self.group)
             self.last_counts = None
             return backward_result
         n, a = ag.shape
@@ -298,8 +311,9 @@ class ShardedTracer:
         self.group = group
         self.bounds = None
         self.sparse = SparseGradExchange(group) if exchange == "sparse" else None
-        if self.sparse is not None and hasattr(pipeline, "gradient_row_pitch"):
-            # rf_compact_grad_rows / rf_scatter_grad_rows read and write the reference's dense [N][A] rows
+        if self.sparse is None and hasattr(pipeline, "gradient_row_pitch") and self._world() > 1:
+            # the dense exchange all-reduces the flat buffer: padding columns (13 -> 16, 28 -> 32, 49 -> 64 floats per
+            # row) would be up to 29 % more xGMI bytes per step; the sparse exchange sends packed rows whatever the pitch
             pipeline.gradient_row_pitch = "dense"
 
     def _world(self):

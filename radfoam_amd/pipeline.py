@@ -280,12 +280,9 @@ class Pipeline:
         #:   True / False      always / never (callers that drive trace_backward by hand, like
         #:                     bench.py, set True).
         self.record_trail = "auto"
-        #: what "auto" cannot see from inside another operator's forward: a caller that optimises ONLY the points
-        #: (attributes frozen) through an autograd.Function -- grad mode is off there and the attributes do not require
-        #: grad, so the heuristic says "no trail" and every backward re-walks.  An operator that knows whether a backward
-        #: will follow sets this around its trace_forward call (radfoam_amd/render.py does, from ctx.needs_input_grad);
-        #: None = use the heuristic.
-        self.backward_hint = None
+        #: (what "auto" cannot see from inside another operator's forward -- a caller that optimises ONLY the points or the
+        #: rays through an autograd.Function: grad mode is off there and the attributes do not require grad -- that operator
+        #: passes as trace_forward's ``record_trail`` argument; radfoam_amd/render.py does)
         #: hops recorded per ray; rays that take more are left to a second launch that walks them again by scanning.
         #: That launch is as long as its longest ray (hundreds of dependent scans): 130 of 1 M rays of the training-shaped
         #: batch take 257-269 hops and cost 1.4 ms of an 8 ms backward.  So the capacity follows the data: every
@@ -347,7 +344,10 @@ class Pipeline:
         self._trail = None
         self._order = None
 
-    def _wants_trail(self, points, attributes) -> bool:
+    #: trace_forward takes the keyword-only ``record_trail`` (radfoam_amd.render.TraceRays passes it)
+    accepts_record_trail = True
+
+    def _wants_trail(self, points, attributes, override=None) -> bool:
         """"auto": will a trace_backward follow this forward?  Inside an autograd.Function.forward grad mode is off and
         the inputs keep their requires_grad flags whether or not the caller runs under torch.no_grad(), so the flags
         of a leaf say nothing: RadFoamScene hands its nn.Parameter points to every render, evaluation included.  What
@@ -356,8 +356,8 @@ class Pipeline:
         where grad mode is the caller's -- points.requires_grad with grad mode on.  A wrong "no" only costs speed
         (trace_backward re-walks instead of replaying), never correctness."""
         if self.record_trail == "auto":
-            if self.backward_hint is not None:      # an operator that knows (ctx.needs_input_grad) said so
-                return bool(self.backward_hint)
+            if override is not None:                # an operator that knows whether a backward follows said so
+                return bool(override)
             return bool(attributes.requires_grad or (points.requires_grad and torch.is_grad_enabled()))
         return bool(self.record_trail)
 
@@ -611,8 +611,10 @@ class Pipeline:
     # -- trace_forward ---------------------------------------------------------------------------
     def trace_forward(self, points, attributes, point_adjacency, point_adjacency_offsets, rays,
                       start_point, depth_quantiles=None, weight_threshold=None,
-                      max_intersections=None, return_contribution=False):
-        """pipeline_bindings.cpp:107-265 (kernel: src/tracing/pipeline.cu:14-130)."""
+                      max_intersections=None, return_contribution=False, *, record_trail=None):
+        """pipeline_bindings.cpp:107-265 (kernel: src/tracing/pipeline.cu:14-130).  ``record_trail`` (keyword only, not
+        in the reference): True / False from a caller that knows whether a trace_backward of these rays will follow
+        (overrides the "auto" heuristic of ``Pipeline.record_trail`` for this call); None = the heuristic."""
         points_c = points.contiguous()
         attributes_c = attributes.contiguous()
         adjacency_c = point_adjacency.contiguous()
@@ -665,7 +667,7 @@ class Pipeline:
         ray_keys = (_source_key(rays, rays_c), _source_key(start_point, start_c), _source_key(depth_quantiles, quantiles_c))
         self._ray_order(opts, rays_c, start_c, num_rays, key=ray_keys[:2])
         trail = None
-        if self._wants_trail(points, attributes):
+        if self._wants_trail(points, attributes, record_trail):
             trail = self._new_trail(opts, num_rays, dev)
         tiles_pending = None
         if opts.image_width:

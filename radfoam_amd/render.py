@@ -25,21 +25,23 @@ class TraceRays(torch.autograd.Function):
     def apply(cls, pipeline, points, attributes, *rest):
         """Whether a backward can follow is known HERE and nowhere below: inside forward() grad mode is off and
         ctx.needs_input_grad only repeats the inputs' requires_grad flags (an nn.Parameter keeps its flag under
-        torch.no_grad()), so Pipeline._wants_trail's "auto" cannot see a caller that optimises only the points.  The
-        caller's grad mode and the two differentiable inputs decide; the pipeline gets the answer as backward_hint."""
-        keep = getattr(pipeline, "backward_hint", None)
-        pipeline.backward_hint = bool(torch.is_grad_enabled() and (points.requires_grad or attributes.requires_grad))
-        try:
-            return super().apply(pipeline, points, attributes, *rest)
-        finally:
-            pipeline.backward_hint = keep
+        torch.no_grad()), so Pipeline._wants_trail's "auto" cannot see a caller that optimises only the points -- or only
+        the rays (a camera).  The caller's grad mode and the differentiable inputs decide; the answer travels to
+        trace_forward as an ARGUMENT (record_trail), nothing on the shared pipeline object is touched: one Pipeline may
+        serve several threads or streams."""
+        rays = rest[2] if len(rest) > 2 else None
+        wanted = bool(torch.is_grad_enabled() and (points.requires_grad or attributes.requires_grad or
+                                                   (torch.is_tensor(rays) and rays.requires_grad)))
+        return super().apply(pipeline, points, attributes, *rest, wanted)
 
     @staticmethod
     def forward(ctx, pipeline, points, attributes, point_adjacency, point_adjacency_offsets, rays,
-                start_point, depth_quantiles, return_contribution):
+                start_point, depth_quantiles, return_contribution, record_trail=None):
+        # (a pipeline object with the reference binding's exact signature is served too: the hint is an extension)
+        extra = {"record_trail": record_trail} if getattr(pipeline, "accepts_record_trail", False) else {}
         out = pipeline.trace_forward(points, attributes, point_adjacency, point_adjacency_offsets, rays,
                                      start_point, depth_quantiles=depth_quantiles,
-                                     return_contribution=return_contribution)
+                                     return_contribution=return_contribution, **extra)
         box = ErrorBox()
         ctx.pipeline = pipeline
         ctx.box = box
@@ -59,4 +61,4 @@ class TraceRays(torch.autograd.Function):
         points_grad.masked_fill_(~points_grad.isfinite(), 0)
         attr_grad.masked_fill_(~attr_grad.isfinite(), 0)
         ctx.foam = ctx.ray_args = ctx.fwd = ctx.pipeline = None
-        return None, points_grad, attr_grad, None, None, None, None, None, None
+        return None, points_grad, attr_grad, None, None, None, None, None, None, None

@@ -190,11 +190,12 @@ def test_balanced_row_blocks():
     assert b[0] == 0 and b[-1] == 64 and all(x < y for x, y in zip(b, b[1:]))
 
 
-def test_sparse_exchange_insists_on_dense_gradient_rows():
-    """Round 4: Pipeline.trace_backward accumulates attr_grad in rows padded to 64-byte lines by default and returns a
-    [N, A] view of them; the exchange kernels (rf_compact_grad_rows / rf_scatter_grad_rows) read and write the reference's
-    dense rows, so ShardedTracer switches its pipeline to gradient_row_pitch = "dense" when it exchanges sparsely, and the
-    exchange refuses a strided attr_grad instead of reading the wrong floats."""
+def test_sparse_exchange_takes_gradient_rows_of_any_pitch():
+    """Pipeline.trace_backward accumulates attr_grad in rows padded to 64-byte lines by default and returns a
+    [N, A] VIEW of them.  The exchange reads the row pitch off the view (rf_compact_grad_rows_pitched /
+    rf_scatter_grad_rows_pitched on the GPU) instead of depending on N's divisibility: the packed rows are the same
+    whether the rows are dense or padded, for N % 16 == 0 and N % 16 != 0; the dense all-reduce is the one that asks for
+    dense rows (when there is more than one rank)."""
     import torch
 
     from radfoam_amd import dist as rdist
@@ -203,13 +204,30 @@ def test_sparse_exchange_insists_on_dense_gradient_rows():
         gradient_row_pitch = "auto"
 
     pipe = _Pipe()
-    rdist.ShardedTracer(pipe, exchange="dense")
-    assert pipe.gradient_row_pitch == "auto"
     rdist.ShardedTracer(pipe, exchange="sparse")
-    assert pipe.gradient_row_pitch == "dense"
+    assert pipe.gradient_row_pitch == "auto"
+    rdist.ShardedTracer(pipe, exchange="dense")             # a single process: nothing to exchange, nothing to change
+    assert pipe.gradient_row_pitch == "auto"
     ex = rdist.SparseGradExchange()
-    n, a = 10, 13
-    padded = torch.zeros(n, 16)[:, :a]
-    send = torch.zeros(n, ex._pitch(a))
-    with pytest.raises(RuntimeError, match="dense"):
-        ex._compact(torch.zeros(n, 3), padded, send, torch.zeros(1, dtype=torch.int32))
+    for n in (32, 37):
+        a = 13
+        g = torch.Generator().manual_seed(n)
+        dense = torch.randn(n, a, generator=g) * (torch.rand(n, 1, generator=g) < 0.4)
+        pg = torch.randn(n, 3, generator=g) * (dense.abs().sum(1, keepdim=True) > 0)
+        padded = torch.zeros(n, 16)
+        padded[:, :a] = dense
+        view = padded[:, :a]
+        assert not view.is_contiguous() and ex._row_pitch(view) == 16 and ex._row_pitch(dense) == a
+        packed = []
+        for rows in (dense, view):
+            send = torch.zeros(n, ex._pitch(a))
+            count = torch.zeros(1, dtype=torch.int32)
+            ex._compact(pg, rows, send, count)
+            k = int(count)
+            packed.append(send[:k].clone())
+            out_pg, out = torch.zeros(n, 3), torch.zeros(n, 16)
+            ex._scatter(send, k, out_pg, out[:, :a], zero=False)
+            assert torch.equal(out[:, :a], dense) and torch.equal(out_pg, pg) and not out[:, a:].any()
+        assert torch.equal(packed[0], packed[1])
+    with pytest.raises(RuntimeError, match="contiguous floats"):
+        ex._row_pitch(torch.zeros(8, 26)[:, ::2])

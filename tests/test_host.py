@@ -423,33 +423,36 @@ def test_trail_capacity_policy_is_bounded_by_memory_and_shrinks():
 
 
 def test_traceraysoperator_tells_the_pipeline_whether_a_backward_follows():
-    """inside an autograd.Function.forward grad mode is off, so Pipeline._wants_trail("auto") cannot see
-    a caller that optimises only the points; radfoam_amd.render.TraceRays passes ctx.needs_input_grad down."""
+    """inside an autograd.Function.forward grad mode is off, so Pipeline._wants_trail("auto") cannot
+    see a caller that optimises only the points -- or only the rays; radfoam_amd.render.TraceRays decides from the
+    caller's grad mode and inputs and passes the answer as trace_forward's record_trail ARGUMENT: the shared pipeline
+    object is not touched (one Pipeline may serve several threads)."""
     from radfoam_amd import render
 
     seen = []
 
     class _Probe:
-        backward_hint = None
+        accepts_record_trail = True
 
-        def trace_forward(self, points, attributes, *a, **k):
-            seen.append(self.backward_hint)
+        def trace_forward(self, points, attributes, *a, record_trail="missing", **k):
+            seen.append(record_trail)
             return {"rgba": points.sum() + torch.zeros(1, 4), "num_intersections": torch.zeros(1, 1)}
 
     pipe = _Probe()
+    before = dict(vars(pipe))
     pts, att = torch.zeros(4, 3), torch.zeros(4, 4)
     none = torch.zeros(0)
     render.TraceRays.apply(pipe, pts.clone().requires_grad_(), att, none, none, none, none, None, False)
     render.TraceRays.apply(pipe, pts, att, none, none, none, none, None, False)
     with torch.no_grad():
         render.TraceRays.apply(pipe, pts.clone().requires_grad_(), att, none, none, none, none, None, False)
-    assert seen == [True, False, False] and pipe.backward_hint is None
+    render.TraceRays.apply(pipe, pts, att, none, none, torch.zeros(2, 6, requires_grad=True), none, None, False)
+    assert seen == [True, False, False, True] and vars(pipe) == before
     import radfoam
     real = radfoam.create_pipeline(0)
-    real.backward_hint = True
-    assert real._wants_trail(pts, att) is True          # points only, grad mode irrelevant
-    real.backward_hint = False
-    assert real._wants_trail(pts.clone().requires_grad_(), att.clone().requires_grad_()) is False
+    assert real._wants_trail(pts, att, True) is True          # points only, grad mode irrelevant
+    assert real._wants_trail(pts.clone().requires_grad_(), att.clone().requires_grad_(), False) is False
+    assert real._wants_trail(pts, att.clone().requires_grad_()) is True and real._wants_trail(pts, att) is False
 
 
 def test_a_strided_view_keeps_its_key_across_contiguous_copies():
