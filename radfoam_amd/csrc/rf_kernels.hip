@@ -2066,6 +2066,55 @@ __device__ __forceinline__ void table_add(unsigned long long *tab, uint32_t key,
     }
 }
 
+// table_add for up to N (key, value) pairs of a lane at once, each into its own table: the N reads go out together, then
+// the N compare-and-swaps, and only the pairs whose swap lost are tried again -- one LDS round trip per attempt for all of
+// a step's scalars (density gradient and the three point-gradient components) instead of one each.
+template <int ROWS, int N>
+__device__ __forceinline__ void table_add_n(unsigned long long (*tab)[ROWS], const uint32_t (&key)[N], const float (&v)[N],
+                                            bool (&todo)[N], float *const (&dst)[N], const size_t (&stride)[N]) {
+    uint32_t slot[N];
+    unsigned long long old[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        slot[i] = (((key[i] * 2654435761u) >> 16) * (uint32_t)ROWS) >> 16;
+        old[i] = todo[i] ? tab[i][slot[i]] : 0ull;
+    }
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) any |= todo[i];
+    while (ballot(any) != 0ull) {
+        unsigned long long seen[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            seen[i] = old[i];
+            if (todo[i]) {
+                const uint32_t okey = (uint32_t)(old[i] >> 32);
+                const float sum = okey == key[i] ? __builtin_bit_cast(float, (uint32_t)old[i]) + v[i] : v[i];
+                const unsigned long long want =
+                    ((unsigned long long)key[i] << 32) | (unsigned long long)__builtin_bit_cast(uint32_t, sum);
+                seen[i] = atomicCAS(&tab[i][slot[i]], old[i], want);
+            }
+        }
+        any = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (todo[i]) {
+                if (seen[i] == old[i]) {
+                    const uint32_t okey = (uint32_t)(old[i] >> 32);
+                    if (okey != key[i] && okey != kNone) {
+                        const float evicted = __builtin_bit_cast(float, (uint32_t)old[i]);
+                        if (evicted != 0.0f) grad_add(dst[i] + stride[i] * (size_t)okey, evicted);
+                    }
+                    todo[i] = false;
+                } else {
+                    old[i] = seen[i];
+                    any = true;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // MODE 4: trail replay with direct, row-coalesced global atomics -- for flat (training-like) batches.
 //
@@ -2081,6 +2130,12 @@ __device__ __forceinline__ void table_add(unsigned long long *tab, uint32_t key,
 // column-major).  The scalars per cell -- the density gradient, one value per segment and 10 of the 13 ms
 // when sent directly, and the three point-gradient components -- go through block-level write-back tables
 // (table_add above; same-cell lanes pre-merged by DPP).
+#ifndef RF_JOINT_TABLES
+#define RF_JOINT_TABLES 0     // measured: 15.35 ms against 14.57 (every segment lit), 6.22 against 5.43: the retries of one table hold the other three
+#endif
+#ifndef RF_ROW_WINDOW
+#define RF_ROW_WINDOW 4      // steps whose colour rows are merged before they are emitted (1, 2, 3, 4, 6 or 8)
+#endif
 template <int DEG, bool HALF, bool QUANT>
 __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void backward_replay_direct_kernel(BwdParams p) {
     constexpr int NB = sh_dim(DEG);
@@ -2114,6 +2169,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
     // degree 3, whose three blocks per CU have the room since the rows are rebuilt from the basis (16 KB + 32 KB): backward
     // of the training batch 5.04 -> 4.89 ms, every segment lit 14.97 -> 14.54; 512: 5.25 / 15.7; 1152: as 1024
     // (profiles/r04/i_table_rows_ab.log)
+    constexpr int kRowWindow = RF_ROW_WINDOW;
     constexpr int DROWS = DEG >= 3 ? (RF_DTABLE_ROWS > 1024 ? RF_DTABLE_ROWS : 1024) : RF_DTABLE_ROWS;
     __shared__ unsigned long long s_tab[4][DROWS];
     for (uint32_t e = threadIdx.x; e < (uint32_t)(4 * DROWS); e += kBlock) (&s_tab[0][0])[e] = kEmptyEntry;
@@ -2131,6 +2187,18 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
 
     StepGrad G;
     clear_step(G);
+    // the steps whose colour rows are still to be emitted (FROM_BASIS with a window): per lane the cell and dL/drgb of each
+    // step, per step the mask of its lit lanes
+    uint32_t hc[kRowWindow];
+    float hr[kRowWindow], hg[kRowWindow], hb[kRowWindow];
+    unsigned long long hm[kRowWindow];
+#pragma unroll
+    for (int w = 0; w < kRowWindow; ++w) {
+        hc[w] = 0u;
+        hr[w] = hg[w] = hb[w] = 0.0f;
+        hm[w] = 0ull;
+    }
+    uint32_t wi = 0;
 #ifdef RF_EXPERIMENT_SECTIONS
     unsigned long long sec_tables = 0, sec_rows = 0, sec_steps = 0, sec_total = __builtin_readcyclecounter();
 #endif
@@ -2143,7 +2211,8 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
 #endif
 
         if (ballot(G.has) != 0ull) {
-            // density gradient: lanes of the wave in the same cell merged (DPP xor stages), then into the block's table
+            // density gradient and the point gradient of the previous cell: lanes of the wave in the same cell merged (DPP
+            // xor stages), then all four scalars into the block's tables in one joint update
             {
                 bool dact = G.has;
                 float dv[1] = {G.dL_ds};
@@ -2151,29 +2220,39 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                 absorb_stage<2, 1>(lane, G.cur, dact, dv);
                 absorb_stage<4, 1>(lane, G.cur, dact, dv);
                 absorb_stage<8, 1>(lane, G.cur, dact, dv);
-                if (dact && dv[0] != 0.0f)
-                    table_add<DROWS>(s_tab[0], G.cur, dv[0], p.attr_grad + (A - 1), (size_t)p.attr_pitch);
-            }
-            // point gradient of the previous cell
-            if (ballot(G.has && G.pg_on) != 0ull) {
                 bool pact = G.has && G.pg_on;
                 float pv[3] = {G.px, G.py, G.pz};
-                absorb_stage<1, 3>(lane, G.prev, pact, pv);
-                absorb_stage<2, 3>(lane, G.prev, pact, pv);
-                absorb_stage<4, 3>(lane, G.prev, pact, pv);
-                absorb_stage<8, 3>(lane, G.prev, pact, pv);
+                if (ballot(pact) != 0ull) {
+                    absorb_stage<1, 3>(lane, G.prev, pact, pv);
+                    absorb_stage<2, 3>(lane, G.prev, pact, pv);
+                    absorb_stage<4, 3>(lane, G.prev, pact, pv);
+                    absorb_stage<8, 3>(lane, G.prev, pact, pv);
+                }
+#if RF_JOINT_TABLES
+                const uint32_t keys[4] = {G.cur, G.prev, G.prev, G.prev};
+                const float vals[4] = {dv[0], pv[0], pv[1], pv[2]};
+                bool todo[4] = {dact && dv[0] != 0.0f, pact && pv[0] != 0.0f, pact && pv[1] != 0.0f, pact && pv[2] != 0.0f};
+                float *const dsts[4] = {p.attr_grad + (A - 1), p.points_grad + 0, p.points_grad + 1, p.points_grad + 2};
+                const size_t strides[4] = {(size_t)p.attr_pitch, (size_t)3, (size_t)3, (size_t)3};
+                table_add_n<DROWS, 4>(s_tab, keys, vals, todo, dsts, strides);
+#else
+                if (dact && dv[0] != 0.0f)
+                    table_add<DROWS>(s_tab[0], G.cur, dv[0], p.attr_grad + (A - 1), (size_t)p.attr_pitch);
                 if (pact) {
                     if (pv[0] != 0.0f) table_add<DROWS>(s_tab[1], G.prev, pv[0], p.points_grad + 0, (size_t)3);
                     if (pv[1] != 0.0f) table_add<DROWS>(s_tab[2], G.prev, pv[1], p.points_grad + 1, (size_t)3);
                     if (pv[2] != 0.0f) table_add<DROWS>(s_tab[3], G.prev, pv[2], p.points_grad + 2, (size_t)3);
                 }
+#endif
             }
 #ifdef RF_EXPERIMENT_SECTIONS
             e1 = __builtin_readcyclecounter();
 #endif
             // colour rows: stage lane-major, emit column-major (two rows per pass, a lane per column)
             const bool lit = G.has && G.row;
-            if constexpr (FROM_BASIS) {
+            if constexpr (FROM_BASIS && kRowWindow > 1) {
+                // recorded below, emitted every kRowWindow steps
+            } else if constexpr (FROM_BASIS) {
                 // (Measured out in round 4, profiles/r04/e_row_emission_pipelined_ab.log: the members of all groups in ONE
                 // loop with the next member's basis value requested before this one's is used -- 5.05 against 5.00 ms, the
                 // wait counter at the loop's back edge makes the compiler wait for the early read anyway.)
@@ -2285,6 +2364,73 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
                         }
                     }
                     __builtin_amdgcn_wave_barrier();   // the slots are rewritten by the next half / next step
+                }
+            }
+        }
+        if constexpr (FROM_BASIS && kRowWindow > 1) {
+            // Colour rows merged over TIME as well as over the wave: the lanes of a wave reach a cell a step or two after
+            // one another, so the (lane, step) pairs of kRowWindow consecutive steps hold far fewer distinct cells than the
+            // steps taken one by one -- on the training batch 0.56 rows per lit segment emitted step by step, 0.43 / 0.36 /
+            // 0.32 over 2 / 3 / 4 steps (scripts/model_row_window.py) -- and with every segment lit the launch is bound by
+            // the rows the memory side's atomic unit takes (section 4.3 of DESIGN.md).  A step leaves {cell, dL/drgb} in
+            // four registers of its lane and its lit lanes as a wave mask; every kRowWindow steps (and when the wave's last
+            // ray ends) the emitting lanes, one per column, rebuild every distinct cell's row from the rays' bases in LDS.
+            // Measured (profiles/r05/b_row_window_ab.log; backward of the training batch, every segment lit / 16 % lit):
+            // 14.75 / 4.93 ms step by step, 12.66 / 4.51 over 2 steps, 12.11 over 3, 11.83 / 4.44 over 4, 11.86 over 6.
+            // Measured out beside it: the members of a row taken four at a time with their LDS reads in flight together
+            // (14.57: a row's members are spread over the window's steps, whose registers differ, so most batches are
+            // mostly padding); the window's dL/drgb in LDS with one member list per row (15.75: 12 KB of LDS per block at
+            // the tables' expense and a scalar gather per member); the step's four table updates as one joint
+            // compare-and-swap round (15.35: the retries of one table hold the other three).
+            const bool litw = G.has && G.row;
+            const unsigned long long lm = ballot(litw);
+            switch (wi) {
+#define RF_RECORD(k) case k: hc[k] = G.cur; hr[k] = G.dLr; hg[k] = G.dLg; hb[k] = G.dLb; hm[k] = lm; break;
+                RF_RECORD(0)
+#if RF_ROW_WINDOW > 1
+                RF_RECORD(1)
+#endif
+#if RF_ROW_WINDOW > 2
+                RF_RECORD(2)
+#endif
+#if RF_ROW_WINDOW > 3
+                RF_RECORD(3)
+#endif
+#if RF_ROW_WINDOW > 4
+                RF_RECORD(4)
+                RF_RECORD(5)
+#endif
+#if RF_ROW_WINDOW > 6
+                RF_RECORD(6)
+                RF_RECORD(7)
+#endif
+#undef RF_RECORD
+                default: break;
+            }
+            wi++;
+            if (wi == (uint32_t)kRowWindow || ballot(W.alive) == 0ull) {
+                wi = 0;
+                const uint32_t bcol = lane / 3u, ccol = lane - 3u * bcol;   // column `lane` = basis bcol, channel ccol
+#pragma unroll
+                for (int w = 0; w < kRowWindow; ++w) {
+                    while (hm[w] != 0ull) {
+                        const int src = __builtin_ctzll(hm[w]);
+                        const uint32_t cell = readlane(hc[w], src);
+                        float v = 0.0f;
+#pragma unroll
+                        for (int u = w; u < kRowWindow; ++u) {
+                            unsigned long long group = hm[u] & ballot(hc[u] == cell);   // step u's lit lanes in this cell
+                            hm[u] &= ~group;
+                            while (group != 0ull) {
+                                const int m = __builtin_ctzll(group);
+                                group &= group - 1ull;
+                                const float gr = readlane_f(hr[u], m), gg = readlane_f(hg[u], m), gb = readlane_f(hb[u], m);
+                                const float gc = ccol == 0u ? gr : (ccol == 1u ? gg : gb);
+                                if (lane < (uint32_t)NC) v += stage[(uint32_t)m * NB + bcol] * gc;
+                            }
+                        }
+                        if (lane < (uint32_t)NC && v != 0.0f) grad_add(p.attr_grad + (size_t)cell * p.attr_pitch + lane, v);
+                    }
                 }
             }
         }
