@@ -328,3 +328,13 @@ def test_train_loop_smoke_on_the_gpu(ref_model):
     assert dens is not None and dens["points_after"] != dens["points_before"] and d["rebuilds"]["full"] == 1
     assert 32 < dens["points_after"] <= int(1.15 * dens["points_before"]) + 1
     assert d["calls_by_section"]["densification:tracer_forward"] == 3                 # one per training view
+
+
+@pytest.mark.gpu
+def test_train_loop_has_something_to_learn(ref_model):
+    """the loop's targets are renders of ANOTHER state of the foam (densities doubled inside a sphere and
+    halved around it, a smooth colour field added), so the reference's own losses, Adam and schedules must bring the loss
+    down -- by more than a third within 80 iterations on this small scene."""
+    d = _loop_case("cuda", 20_000, 3, iterations=80, rays_per_batch=30_000, cameras=3, width=160, height=120,
+                   densify_at=10 ** 9)
+    assert d["loss_last"] < 0.66 * d["loss_first"], d["loss_trace"]
