@@ -64,10 +64,10 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3  # 256 CUs x 128 FMA lanes x 2 flop x 2.4 GHz (s
 # actually issued (SQ_INSTS_VALU): issue-slot EFFICIENCY, next to valu_issue_frac, which is issue-slot UTILISATION.
 # The literals are what the committed file holds; isa_constants() refuses to quote them when the file disagrees or was
 # made from other sources.
-SCAN_VALU_PER_4_FACES = 59
-SCAN_FLOP_PER_4_FACES = 72
-HOP_VALU_PER_LANE = 82
-COMPOSITE_VALU_PER_LANE = 59
+SCAN_VALU_PER_4_FACES = 67
+SCAN_FLOP_PER_4_FACES = 92
+HOP_VALU_PER_LANE = 93
+COMPOSITE_VALU_PER_LANE = 60
 
 
 def isa_constants():

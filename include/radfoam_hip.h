@@ -103,7 +103,9 @@ typedef struct rf_launch_opts {
                               /*   instance the others are tested against, 40 % slower.  rf_trace_benchmark honours 3;       */
                               /*   rf_trace_backward accepts and ignores the field (a trail replays under any mode).         */
                               /*   4 (rf_trace_forward, experiment) = persistent waves that refill their dead lanes from  */
-                              /*   a queue by ballot + prefix count -- slower on every workload measured;                  */
+                              /*   a queue by ballot + prefix count -- slower on every workload measured.  The queue head   */
+                              /*   is a word of the workspace: two mode-4 launches that share a workspace must be on ONE    */
+                              /*   stream.  With depth quantiles or `stats` the launch falls back to mode 1.                */
                               /*   5 = mode 2 behind a block-level LDS table of cell records + face blocks (what auto     */
                               /*   picks for a flat batch given with a ray_order: its 256-slot groups re-visit cells).    */
     /* Optional: device uint32[rf_launch_blocks(...)], the tile each block of the launch walks -- a 16x16-pixel tile of   */

@@ -6,7 +6,7 @@
 // the foam so that a hop costs ONE dependent round trip and the face scan no unpacking:
 //
 //   workspace = [ float4 cells[N] | half geo[3 * EB] | Link link[EB] | uint32 nbr[EB] | uint32 poff[N+1] |
-//                 uint32 scan scratch | SH rows[N][sh_stride] (optional) ]
+//                 uint32 scan scratch | uint32 ray queue head | SH rows[N][sh_stride] (optional) ]
 //
 //   Every cell's face list is padded to a multiple of 4 entries; poff[i] is the first (padded)
 //   entry of cell i and poff[N] = E' <= EB = E + 3N the padded total.  Entries past a cell's real
@@ -50,6 +50,7 @@ struct FoamLayout {
     size_t nbr_off;
     size_t poff_off;
     size_t scan_off;     // per-chunk sums of the prefix sum
+    size_t queue_off;    // one uint32: the ray queue head of the persistent-wave forward (forward_mode 4)
     size_t max_entries;  // EB: upper bound of the padded entry count
     size_t sh_off;       // 0 when rows are read in place
     uint32_t sh_stride;  // scalars per SH row as the kernels see it
@@ -88,6 +89,8 @@ inline FoamLayout foam_layout(uint32_t num_points, uint32_t adj_size, int sh_deg
     off = align_up(off + ((size_t)num_points + 1) * 4, 256);
     L.scan_off = off;
     off = align_up(off + ((size_t)num_points / kScanChunk + 2) * 4, 256);
+    L.queue_off = off;
+    off += 256;
     if (L.sh_repacked) {
         L.sh_off = off;
         off = align_up(off + (size_t)num_points * L.sh_stride * (attr_half ? 2 : 4), 256);

@@ -3041,7 +3041,7 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     p.visit_marks = opts->stats ? opts->visit_marks : nullptr;
     p.tile_cost = opts->tile_cost;
     // the scan scratch of the packing (per-chunk sums) is free once the foam is packed: its first word is the queue head
-    p.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(opts->workspace) + L.scan_off);
+    p.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(opts->workspace) + L.queue_off);
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: trail_slots smaller than rf_trail_slots()");

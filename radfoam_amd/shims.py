@@ -242,8 +242,21 @@ class BatchFetcher:
         nbytes = data.numel() * data.element_size()
         self._native = (self.device.type == "cuda" and data.size(0) > 0 and self._row_bytes % 4 == 0 and self._row_bytes > 0
                         and (data.is_cuda or nbytes <= self.device_resident_limit))
+        if self._native and not data.is_cuda:
+            # the copy must FIT: at most half of what the device has free right now (three fetchers -- rays, colours,
+            # alphas -- are made one after the other, and the scene needs its share); a box whose memory is taken falls back
+            # to the host gather instead of failing in the constructor
+            try:
+                free, _total = torch.cuda.mem_get_info(self.device)
+                if nbytes > free // 2:
+                    self._native = False
+                else:
+                    data = data.to(self.device).contiguous()
+            except (torch.cuda.OutOfMemoryError, RuntimeError):
+                self._native = False
+        elif self._native:
+            data = data.contiguous()
         if self._native:
-            data = data.to(self.device if not data.is_cuda else data.device).contiguous()
             self.device = data.device
         self.data = data
 

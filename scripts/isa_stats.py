@@ -58,7 +58,22 @@ def loop_counts(body):
         depth_of[(a, b)] = depth
     ops = lambda a, b: [l.strip().split()[0] for l in lines[a:b] if is_ins(l)]
     valu = lambda o: sum(1 for x in o if x.startswith("v_"))
-    scan = [x for (a, b), d in depth_of.items() if d == 2 for x in ops(a, b)]
+    # the kernels hold TWO inner loops: the filtered scan (first in program order: one block of four faces per trip) and the
+    # dividing scan that resolves contested cells (rare: its trips are not what a wave-step costs)
+    header_of = {}
+    cur_header = None
+    for a, b in zip(starts[:-1], starts[1:]):
+        note = lines[a] + " " + (lines[a + 1] if a + 1 < len(lines) and lines[a + 1].lstrip().startswith(";") else "")
+        if "Inner Loop Header: Depth=2" in note:
+            cur_header = lines[a].split(":")[0]
+            header_of[(a, b)] = cur_header
+        else:
+            m = re.search(r"in Loop: Header=(\S+) Depth=2", note)
+            if m:
+                header_of[(a, b)] = ".L" + m.group(1) if not m.group(1).startswith(".L") else m.group(1)
+    inner = [k for k, d in sorted(depth_of.items()) if d == 2]
+    first = header_of.get(inner[0]) if inner else None
+    scan = [x for k in inner if header_of.get(k) == first for x in ops(*k)]
     # a wave-step outside the scan: the hop (link, next cell record, trail entry, loop bookkeeping) and -- recognisable by
     # what only they contain -- the compositing blocks: the colour-row gather (>= 3 dwordx4 loads), exp (v_ldexp_f32),
     # the contribution atomic

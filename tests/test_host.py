@@ -310,7 +310,7 @@ def test_isa_constants_file_matches_bench_literals_and_says_which_sources():
     assert rec["composite_valu_per_lane"] == bench.COMPOSITE_VALU_PER_LANE
     got, why = bench.isa_constants()
     if rec["csrc_sha256"] == hip_build.source_hash():
-        assert why is None and got["scan_valu_per_4_faces"] == 59
+        assert why is None and got["scan_valu_per_4_faces"] == bench.SCAN_VALU_PER_4_FACES
     else:
         assert got is None and "other kernel sources" in why
         pytest.xfail("kernel sources changed after profiles/isa_constants.json was made: python scripts/isa_stats.py --constants")
