@@ -145,6 +145,9 @@ inline __host__ __device__ uint32_t dealt_tile(uint32_t b, uint32_t chunk, uint3
     // rounds are visited from both ends of the image towards its middle (0, last, 1, last-1, ...):
     // the blocks still running when the launch drains are then neighbours in the image, of
     // similar length, instead of the longest walks of the frame
+#ifdef RF_DEAL_MIDDLE_FIRST
+    j = rounds - 1u - j;       // experiment: the same sequence backwards -- the middle of the image first, its ends last
+#endif
     j = (j & 1u) ? rounds - 1u - (j >> 1) : (j >> 1);
     return (j * 8u + ((x + 3u * j) & 7u)) * chunk + o;
 }
@@ -824,6 +827,9 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
     bool fetched = alive;   // CACHED: head / GB of the current cell came from memory, the table may want them
     uint32_t wave_steps = 0;
     uint32_t hops = 0;
+    uint32_t trail_step = 0;             // wave-uniform: steps taken so far = hops of every lane still alive
+    uint32_t *trail_row = p.trail;       // wave-uniform: row `trail_step` of the trail
+    const uint32_t slot4 = slot * 4u;    // the lane's byte offset in a row (rf_trace_forward refuses rows of 4 GB and more)
     while (ballot(alive) != 0ull) {
         wave_steps++;
         if (alive) {
@@ -884,8 +890,11 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
             if constexpr (!BENCH) {
                 // trail: the cell each hop enters, for trace_backward to replay
                 if (p.trail) {
-                    if (hops < p.trail_cap) p.trail[(size_t)hops * p.trail_slots + slot] = cur;
-                    hops++;
+                    // every lane that is still alive has hopped in every step so far: hop number = step number, the same
+                    // for the whole wave -- the trail row is a scalar base, the lane adds its slot (a 32-bit offset)
+                    if (trail_step < p.trail_cap)
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(trail_row) + slot4) = cur;
+                    hops = trail_step + 1u;
                 }
             }
         }
@@ -925,6 +934,8 @@ __global__ __launch_bounds__(kBlock, forward_waves(DEG, HALF, QUANT, STATS, SCAN
             }
             t0 = segment ? t1 : t0;     // fmaxf(t0, t1): t0 is never NaN
         }
+        trail_step++;
+        if (trail_row) trail_row += p.trail_slots;
     }
 
     if constexpr (!BENCH) {
@@ -1822,6 +1833,8 @@ struct TrailWalker {
     float4 head, q0;
     uint32_t cur, hops, recorded, i, n, id0, id1, slot;
     size_t slots;
+    // (measured out in round 5: reading the trail through a wave-uniform row pointer + the lane's 32-bit offset, as the
+    // forward writes it -- the image backward went from 3.76 to 3.92 ms, the flat one did not move)
     bool alive;
 #ifdef RF_EXPERIMENT_SECTIONS
     unsigned long long sec_wait = 0, sec_segment = 0;   // wave clocks: until the hop's records are there / in backward_segment
@@ -3045,6 +3058,8 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: trail_slots smaller than rf_trail_slots()");
+        if (opts->trail_slots >= (1u << 30))
+            return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_forward: a trail row of 4 GB or more (2^30 slots) is not addressable");
         p.trail = opts->trail;
         p.trail_hops = opts->trail_hops;
         p.trail_cap = opts->trail_cap;
@@ -3111,6 +3126,8 @@ int rf_trace_backward(int sh_degree, int attr_type, const rf_trace_settings *set
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
             return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: trail_slots smaller than rf_trail_slots()");
+        if (opts->trail_slots >= (1u << 30))
+            return fail(RF_ERR_INVALID_ARGUMENT, "rf_trace_backward: a trail row of 4 GB or more (2^30 slots) is not addressable");
         p.trail = opts->trail;
         p.trail_hops = opts->trail_hops;
         p.trail_cap = opts->trail_cap;
