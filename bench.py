@@ -961,14 +961,18 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
         cut = lambda a: None if a is None else np.ascontiguousarray(a[sl])
         return cut(rays_np), cut(start_np), cut(g_np), sl, cut(q_np), cut(dg_np)
 
+    contested = {}
+
     def run(stride):
         r, s, g, sl, q, dg = sample(stride)
         # the scan evaluated the way the kernels evaluate it (tournament on products + certificate + dividing fallback:
         # the same function as the reference's evaluation, tests/test_oracle.py, and twice as fast on these cores)
-        with O.scan_mode("filtered"):
+        with O.scan_mode("filtered") as mode:
             t0 = time.perf_counter()
             f = O.trace_forward(*foam_args, r, s, depth_quantiles=q, diff=diff, num_threads=cores)
             t1 = time.perf_counter()
+            contested["cells"] = mode.contested      # cells whose certificate failed (the dividing scan decided)
+            contested["scans"] = int(f["num_intersections"].sum())
             b = None
             if not W["forward_only"]:
                 b = O.trace_backward(*foam_args, r, s, f["rgba"], g, depth_quantiles=q,
@@ -1017,6 +1021,9 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
                     f"in the walk, BASELINE.md section 3), the scan evaluated as the kernels evaluate it; forward {tf:.2f}s"
                   + ("" if b is None else f" + backward {tb:.2f}s") + "; fp16 face table prebuilt (excluded)",
         "matches_gpu_bitwise": same,
+        # how often the filtered scan's certificate fails on this workload (the same evaluation the kernels run)
+        "scan_contested_cells": contested.get("cells"), "scan_cells": contested.get("scans"),
+        "scan_contested_rate": (round(contested["cells"] / max(contested["scans"], 1), 7) if contested else None),
     }
     try:
         env = reference_source_envelope(W, fm)
