@@ -66,8 +66,8 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3  # 256 CUs x 128 FMA lanes x 2 flop x 2.4 GHz (s
 # made from other sources.
 SCAN_VALU_PER_4_FACES = 67
 SCAN_FLOP_PER_4_FACES = 92
-HOP_VALU_PER_LANE = 93
-COMPOSITE_VALU_PER_LANE = 60
+HOP_VALU_PER_LANE = 92
+COMPOSITE_VALU_PER_LANE = 61
 
 
 def isa_constants():
