@@ -1368,7 +1368,10 @@ __device__ __forceinline__ void init_backward_ray(BwdRay &R) {
 
 // The backward functor for the segment [t0,t1] of cell `cur` (reference: pipeline.cu:180-331).
 // Returns false when the ray terminates (transmittance below the threshold).
-template <int DEG, bool HALF, bool QUANT = true>
+// PAIRS: the four bisector gradients as two shared evaluations (bisector_grad_pair) -- the same floats; worth it where
+// registers are to spare (flat-batch replay: 4.47 -> 4.40 ms, every segment lit 11.98 -> 11.76), a loss where they are not
+// (image replay at its 128-VGPR limit: 3.77 -> 3.99 ms, the shared values spill; profiles/r05/e_bisector_pairs_ab.log)
+template <int DEG, bool HALF, bool QUANT = true, bool PAIRS = false>
 __device__ __forceinline__ bool backward_segment(const BwdParams &p, BwdRay &R, const float (&sh)[sh_dim(DEG)],
                                                  uint32_t cur, float4 head, float4 nhead, float t1,
                                                  StepGrad &G) {
@@ -1426,14 +1429,24 @@ __device__ __forceinline__ bool backward_segment(const BwdParams &p, BwdRay &R, 
     // (Differs from the reference only if a bisector gradient is non-finite there: 0 * inf.)
     if (dL_dt0 != 0.0f || dL_dt1 != 0.0f) {
         float ax = 0.0f, ay = 0.0f, az = 0.0f;  // dt0_dprev
-        if (R.prev != kNone)
-            bisector_grad(R.ppx, R.ppy, R.ppz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ax, ay, az);
         float bx, by, bz;                        // dt1_dcurrent
-        bisector_grad(head.x, head.y, head.z, nhead.x, nhead.y, nhead.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, bx, by, bz);
-        float ex, ey, ez;                        // dt0_dcurrent (vs prev, or vs origin on the first segment)
-        bisector_grad(head.x, head.y, head.z, R.ppx, R.ppy, R.ppz, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ex, ey, ez);
+        float ex, ey, ez;                        // dt0_dcurrent (vs prev, or vs the world origin on the first segment)
         float fx, fy, fz;                        // dt1_dnext
-        bisector_grad(nhead.x, nhead.y, nhead.z, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, fx, fy, fz);
+        if constexpr (PAIRS) {
+            // the four gradients are two pairs over the same plane each -- (prev, cur) and (cur, next) --: one evaluation
+            // per plane gives both, bit for bit what four separate evaluations return (rf_math.hpp)
+            bisector_grad_pair(R.ppx, R.ppy, R.ppz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ax, ay, az,
+                               ex, ey, ez);
+            if (R.prev == kNone) ax = ay = az = 0.0f;
+            bisector_grad_pair(head.x, head.y, head.z, nhead.x, nhead.y, nhead.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, bx, by,
+                               bz, fx, fy, fz);
+        } else {
+            if (R.prev != kNone)
+                bisector_grad(R.ppx, R.ppy, R.ppz, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ax, ay, az);
+            bisector_grad(head.x, head.y, head.z, nhead.x, nhead.y, nhead.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, bx, by, bz);
+            bisector_grad(head.x, head.y, head.z, R.ppx, R.ppy, R.ppz, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, ex, ey, ez);
+            bisector_grad(nhead.x, nhead.y, nhead.z, head.x, head.y, head.z, R.Ox, R.Oy, R.Oz, R.dx, R.dy, R.dz, fx, fy, fz);
+        }
 
         R.pgx = fma_(dL_dt0, ax, R.pgx);
         R.pgy = fma_(dL_dt0, ay, R.pgy);
@@ -1825,7 +1838,7 @@ __device__ __forceinline__ void cache_flush(double *rows, uint32_t *keys, uint8_
 // The per-lane state of a trail replay and one hop of it, shared by the replay kernels below.
 // Pipeline registers: id1 = trail[i+1], id0 = trail[i], q0 = cells[id0]; every call of step()
 // issues the loads of hop i+1 / i+2 first and then computes hop i from registers.
-template <int DEG, bool HALF, bool QUANT>
+template <int DEG, bool HALF, bool QUANT, bool PAIRS = false>
 struct TrailWalker {
     static constexpr int NB = sh_dim(DEG);
     BwdRay R;
@@ -1903,7 +1916,7 @@ struct TrailWalker {
 #endif
         if (alive) {
             if (t1 > R.t0) {
-                if (!backward_segment<DEG, HALF, QUANT>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
+                if (!backward_segment<DEG, HALF, QUANT, PAIRS>(p, R, sh, cur, head, nhead, t1, G)) alive = false;
             }
 #ifdef RF_EXPERIMENT_SECTIONS
             asm volatile("" : "+v"(G.dL_ds));
@@ -2188,7 +2201,7 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
     for (uint32_t e = threadIdx.x; e < (uint32_t)(4 * DROWS); e += kBlock) (&s_tab[0][0])[e] = kEmptyEntry;
     __syncthreads();
 
-    TrailWalker<DEG, HALF, QUANT> W;
+    TrailWalker<DEG, HALF, QUANT, true> W;
     W.init(p);
     const float (&sh)[NB] = W.sh;
     if constexpr (FROM_BASIS) {

@@ -149,6 +149,40 @@ __device__ __forceinline__ void div3_guarded(float nx, float ny, float nz, float
     div3(__builtin_ldexpf(nx, sc), __builtin_ldexpf(ny, sc), __builtin_ldexpf(nz, sc), __builtin_ldexpf(den, sc), qx, qy, qz);
 }
 
+// Both gradients of one bisector hit -- d(t)/d(p) and d(t)/d(q) of the ray's crossing of the bisector of (p, q) -- as
+// bisector_grad(p, q, ...) and bisector_grad(q, p, ...) would return them, bit for bit, at little more than the cost of
+// one: swapping p and q negates the normal, num and dp exactly (every rounding on the way is sign-symmetric) and leaves
+// the midpoint and dp^2 alone, so the two calls share everything but their three numerators and the last steps of the
+// divide.  The backward functor needs exactly such pairs: (prev, cur) and (cur, next) (pipeline.cu:243-262).
+__device__ __forceinline__ void bisector_grad_pair(float px, float py, float pz, float qx, float qy, float qz, float ox,
+                                                   float oy, float oz, float dx, float dy, float dz, float &gpx, float &gpy,
+                                                   float &gpz, float &gqx, float &gqy, float &gqz) {
+    float fnx = qx - px, fny = qy - py, fnz = qz - pz;
+    float vx = (px + qx) / 2.0f - ox;
+    float vy = (py + qy) / 2.0f - oy;
+    float vz = (pz + qz) / 2.0f - oz;
+    float num = dot3(vx, vy, vz, fnx, fny, fnz);
+    float dp = dot3(fnx, fny, fnz, dx, dy, dz);
+    float den = dp * dp;
+    // div3's sequence with the reciprocal shared by six numerators
+    float y = __builtin_amdgcn_rcpf(den);
+    float e = fma_(-den, y, 1.0f);
+    y = fma_(e, y, y);
+    const float n[6] = {fma_(num, dx, dp * (ox - px)), fma_(num, dy, dp * (oy - py)), fma_(num, dz, dp * (oz - pz)),
+                        fma_(num, dx, dp * (ox - qx)), fma_(num, dy, dp * (oy - qy)), fma_(num, dz, dp * (oz - qz))};
+    float g[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float q = n[i] * y;
+        float r = fma_(-den, q, n[i]);
+        q = fma_(r, y, q);
+        r = fma_(-den, q, n[i]);
+        g[i] = fma_(r, y, q);
+    }
+    gpx = g[0]; gpy = g[1]; gpz = g[2];
+    gqx = -g[3]; gqy = -g[4]; gqz = -g[5];
+}
+
 // d(t)/d(primal) of the ray/bisector(primal,opposite) hit; reference: cell_intersection_grad,
 // src/tracing/tracing_utils.cuh:91-103 (uses the fp32 points, not the fp16 face table).
 __device__ __forceinline__ void bisector_grad(float px, float py, float pz, float qx, float qy,
