@@ -1057,3 +1057,55 @@ def test_backward_of_a_strided_ray_view_replays_the_trail(foam_factory):
     for key in ("points_grad", "attr_grad", "point_error"):
         ok, rel, worst = H.grad_close(outs[0][1][key].cpu().numpy(), outs[1][1][key].cpu().numpy())
         assert ok and rel < 1e-5, (key, rel, worst)
+
+
+def test_writes_autograd_cannot_see_need_cache_foam_off_or_invalidate(foam_factory):
+    """the Pipeline keeps the packed foam between calls, keyed on tensor identity + `_version`
+    -- a deliberate deviation from the reference's stateless binding.  A write behind autograd's back (`param.data.add_`)
+    changes neither, so a caching pipeline goes on tracing the OLD foam until `invalidate()`; with `cache_foam = False`
+    (the reference's behaviour: repack on every call) every call sees the memory as it is.  Forward outputs and gradients
+    against the oracle on the moved points, both ways."""
+    d = 1
+    fm = foam_factory(5000, d, 31)
+    cam, rays, start = H.camera_setup(fm, 64, 48)
+    g = np.random.default_rng(2).normal(size=rays.shape[:-1] + (4,)).astype(np.float32)
+    shift = (np.random.default_rng(3).normal(size=fm["points"].shape) * 2e-4).astype(np.float32)   # the lists stay Delaunay-valid enough to walk
+    moved = dict(fm)
+    moved["points"] = fm["points"] + shift
+    args0 = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    args1 = (d, moved["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    ref0 = O.trace_forward(*args0, rays, start)
+    ref1 = O.trace_forward(*args1, rays, start)
+    bwd1 = O.trace_backward(*args1, rays, start, ref1["rgba"], g)
+    assert not np.array_equal(ref0["rgba"], ref1["rgba"])
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    r = torch.from_numpy(rays).to(DEV)
+    s = torch.full(r.shape[:-1], int(start), dtype=torch.int64).to(torch.uint32).to(DEV)
+    same = lambda out, ref: np.array_equal(out["rgba"].cpu().numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+
+    def check_moved(pipe):
+        f = pipe.trace_forward(p, a, adj, off, r, s)
+        assert same(f, ref1)
+        out = pipe.trace_backward(p, a, adj, off, r, s, f["rgba"], torch.from_numpy(g).to(DEV))
+        for key in ("points_grad", "attr_grad"):
+            ok, rel, worst = H.grad_close(out[key].cpu().numpy(), bwd1[key])
+            assert ok and rel < 1e-5, (key, rel, worst)
+
+    # 1. the reference's behaviour: nothing cached
+    pipe = _pipeline(d)
+    pipe.cache_foam = False
+    assert same(pipe.trace_forward(p, a, adj, off, r, s), ref0)
+    version = p._version
+    p.data.add_(torch.from_numpy(shift).to(DEV))
+    assert p._version == version                      # the write is invisible to the version counter
+    check_moved(pipe)
+    # 2. the default: the stale foam until invalidate()
+    p.data.sub_(torch.from_numpy(shift).to(DEV))
+    p.data.copy_(torch.from_numpy(fm["points"]).to(DEV))
+    pipe = _pipeline(d)
+    assert pipe.cache_foam
+    assert same(pipe.trace_forward(p, a, adj, off, r, s), ref0)
+    p.data.copy_(torch.from_numpy(moved["points"]).to(DEV))
+    assert same(pipe.trace_forward(p, a, adj, off, r, s), ref0)     # documented: the packed copy of the old points
+    pipe.invalidate()
+    check_moved(pipe)
