@@ -26,7 +26,7 @@
  *                               + make_rgba8                   src/tracing/camera.h:56-85,
  *                                                              src/tracing/tracing_utils.cuh:105-115
  *
- * CANONICAL ARITHMETIC.  The CUDA build is fp32 with nvcc's default FMA contraction,
+ * PINNED ARITHMETIC.  The CUDA build is fp32 with nvcc's default FMA contraction,
  * IEEE divide/sqrt and CUDA's libm; none of that is reproducible bit-for-bit elsewhere.
  * This oracle pins ONE concrete evaluation so that the HIP kernels can be compared exactly:
  *   - fp32 throughout, compile with -ffp-contract=off, every fused op written as fmaf();
@@ -279,7 +279,7 @@ static void rfo_wc_free(rfo_wc_t *t) {
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* float32 canonical instance                                                            */
+/* float32 instance (the pinned arithmetic)                                             */
 
 #define REAL float
 #define SUF(name) name##_f32

@@ -3,7 +3,7 @@ same seeded inputs.
 
 Tolerances (north star: 1e-4 RGB, 1e-3 relative gradient):
   * forward outputs of fp32 pipelines -- rgba, depth, depth_indices, num_intersections -- must be
-    BIT-IDENTICAL to the oracle (both evaluate the same canonical fp32 arithmetic, DESIGN.md);
+    BIT-IDENTICAL to the oracle (both evaluate the same pinned fp32 arithmetic, DESIGN.md section 2);
   * scatter outputs (contribution, points_grad, attr_grad, point_error) are sums whose order
     differs (atomics): rtol 1e-3 per element (helpers.grad_close), and 1e-5 relative L2.
 """
