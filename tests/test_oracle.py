@@ -5,6 +5,8 @@ checked by (i) closed-form cases, (ii) invariants of the algorithm, (iii) a floa
 (iv) central finite differences of the twin's forward against its backward, and (v) the exact
 form of each documented quirk of the reference's backward (strict vs clean).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -303,3 +305,41 @@ def test_filtered_evaluation_on_degenerate_geometry(case):
     np.testing.assert_array_equal(a["rgba"].view(np.uint32), b["rgba"].view(np.uint32))
     if case in ("grid", "axis_rays"):
         assert contested > 0                                   # a lattice is nothing but ties
+
+
+def test_the_certificate_threshold_is_not_decorative(tmp_path):
+    """The filtered evaluation hands a cell to the dividing scan when two compared products are at most 3 floats apart
+    (proved sufficient in rf_kernels.hip, "the face scan").  Built with the threshold at 0 (only EQUAL products are
+    contested) the mirror must disagree with the reference's evaluation on some rays of a 230,400-ray frame -- otherwise the
+    tests above could not tell a certificate from none; at the shipped threshold it agrees on all of them."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(O.__file__))
+    lib0 = str(tmp_path / "liboracle_tie0.so")
+    subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", "-mfma",
+                    "-DRFO_TIE_ULPS=0u", os.path.join(here, "rf_oracle.c"), "-o", lib0, "-shared", "-lm"], check=True)
+    script = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import oracle as O
+if sys.argv[1] != "shipped":
+    O._LIB_PATH = sys.argv[1]; O.build = lambda *a, **k: None
+import helpers as H
+from radfoam_amd import foam
+fm = foam.make_synthetic_foam(60000, 2, 7)
+cam, rays, start = H.camera_setup(fm, 640, 360)
+args = (2, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+a = O.trace_forward(*args, rays, start)
+with O.scan_mode("filtered") as m:
+    b = O.trace_forward(*args, rays, start)
+    c = m.contested
+print(json.dumps({"contested": c, "rays_differing": int((a["num_intersections"] != b["num_intersections"]).sum())}))
+""" % (os.path.dirname(here), os.path.dirname(os.path.abspath(__file__)))
+    import json
+    out = {}
+    for name in (lib0, "shipped"):
+        r = subprocess.run([sys.executable, "-c", script, name], capture_output=True, text=True, check=True)
+        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out[lib0]["rays_differing"] >= 3, out                 # observed 19
+    assert out["shipped"]["rays_differing"] == 0 and out["shipped"]["contested"] > out[lib0]["contested"], out
