@@ -770,7 +770,7 @@ def test_kernel_evaluates_the_references_scan_on_a_frame_with_contested_cells(fo
         contested = m.contested
     assert contested >= 20, contested                       # observed: ~250 of 2.9e6 cell scans
     np.testing.assert_array_equal(mirror["rgba"].view(np.uint32), ref["rgba"].view(np.uint32))
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4, 5):      # filtered: blocks / eager / persistent / cached instances; 3: every face divided
         pipe = _pipeline(d)
         pipe.forward_mode = mode
         got, _ = _run_forward(pipe, fm, rays, start)
