@@ -343,3 +343,52 @@ print(json.dumps({"contested": c, "rays_differing": int((a["num_intersections"] 
         out[name] = json.loads(r.stdout.strip().splitlines()[-1])
     assert out[lib0]["rays_differing"] >= 3, out                 # observed 19
     assert out["shipped"]["rays_differing"] == 0 and out["shipped"]["contested"] > out[lib0]["contested"], out
+
+
+def test_certificate_on_adversarial_pairs_of_quotients():
+    """The statement the certificate rests on, tested where it is tight instead of where frames happen to go: for
+    fp32 (num_a, dp_a), (num_b, dp_b) with dp > 0, let p1 = RN(num_a * dp_b), p2 = RN(num_b * dp_a) and D the distance of
+    their bit patterns.  If D >= 4 then RN(num_a / dp_a) and RN(num_b / dp_b) are STRICTLY ordered the way p1 and p2
+    are (rf_kernels.hip "the face scan": no tie, so no lowest-index rule to get wrong, and the divided scan would have
+    picked the same face).  4e7 pairs constructed so that the two quotients are 0-12 ulp apart, across 60 binades of
+    every operand, both signs of num, products on either side of a power of two (where the ulp halves).  The converse
+    is also shown: among pairs at D <= 3 the products DO misorder or tie rounded quotients -- the fallback is needed --
+    and the bound is within two of tight: a certificate at D >= 2 lets wrong orders through (observed: D >= 1 222,634,
+    D >= 2 2,855, D >= 3 none of 1.9e7 pairs, D >= 4 -- shipped, proved -- none)."""
+    rng = np.random.default_rng(2024)
+    n = 4_000_000
+    violations = 0
+    certified = 0
+    needed = 0
+    loose = 0
+    with np.errstate(over="ignore", under="ignore"):
+        for rnd in range(10):
+            def operand(sign=False):
+                m = rng.uniform(1.0, 2.0, n)
+                if rnd % 2:                                # half the rounds: mantissas crowded at the binade's ends
+                    m = np.where(rng.random(n) < 0.5, 1.0 + rng.uniform(0, 2.0 ** -20, n), 2.0 - rng.uniform(0, 2.0 ** -20, n))
+                x = m * 2.0 ** rng.integers(-30, 31, n)
+                return (x * (rng.choice([-1.0, 1.0], n) if sign else 1.0)).astype(np.float32)
+            na, da, db = operand(True), operand(), operand()
+            # num_b so that num_b/db is within a few ulp of num_a/da: exact target in float64, then a step of k floats
+            target = (na.astype(np.float64) / da.astype(np.float64) * db.astype(np.float64)).astype(np.float32)
+            k = rng.integers(-12, 13, n).astype(np.int32)
+            bits = target.view(np.int32) + np.where(target < 0, -k, k)
+            nb = bits.view(np.float32)
+            ok = np.isfinite(nb) & (nb != 0) & (np.sign(nb) == np.sign(na))
+            na, da, db, nb = na[ok], da[ok], db[ok], nb[ok]
+            # RN of an fp32 x fp32 product: exact in float64 (48 bits), one rounding to fp32
+            p1 = (na.astype(np.float64) * db.astype(np.float64)).astype(np.float32)
+            p2 = (nb.astype(np.float64) * da.astype(np.float64)).astype(np.float32)
+            dist = np.abs(p1.view(np.uint32).astype(np.int64) - p2.view(np.uint32).astype(np.int64))
+            qa, qb = na / da, nb / db                   # IEEE fp32 divisions: what the reference compares
+            sure = dist >= 4
+            certified += int(sure.sum())
+            wrong = sure & (((p1 < p2) != (qa < qb)) | (qa == qb))
+            violations += int(wrong.sum())
+            needed += int((~sure & (((p1 < p2) != (qa < qb)) | (qa == qb))).sum())
+            loose += int(((dist >= 2) & (((p1 < p2) != (qa < qb)) | (qa == qb))).sum())
+    assert certified > 20_000_000, certified
+    assert violations == 0, violations
+    assert needed > 100_000, needed                     # below the threshold the products alone do get it wrong
+    assert loose > 1000, loose                          # ... and two floats of distance are not enough
