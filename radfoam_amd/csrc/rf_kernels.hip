@@ -2407,7 +2407,10 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
             // (14.57: a row's members are spread over the window's steps, whose registers differ, so most batches are
             // mostly padding); the window's dL/drgb in LDS with one member list per row (15.75: 12 KB of LDS per block at
             // the tables' expense and a scalar gather per member); the step's four table updates as one joint
-            // compare-and-swap round (15.35: the retries of one table hold the other three).
+            // compare-and-swap round (15.35: the retries of one table hold the other three); two / four rows in flight with
+            // their member loops interleaved (12.12 / 14.02 against 11.61, r_rows_in_flight_ab.log) -- which showed that the
+            // emission is bound by what it ISSUES, not by a member's LDS round trip.  Hence the member loop below: 13
+            // instructions per member instead of 24 (s_lean_member_loop_ab.log: 11.62 -> 10.56 / 4.38 -> 4.05 ms).
             const bool litw = G.has && G.row;
             const unsigned long long lm = ballot(litw);
             switch (wi) {
@@ -2437,24 +2440,31 @@ __global__ __launch_bounds__(kBlock, (DEG <= 2 ? 4 : RF_DIRECT_WAVES_D3)) void b
             if (wi == (uint32_t)kRowWindow || ballot(W.alive) == 0ull) {
                 wi = 0;
                 const uint32_t bcol = lane / 3u, ccol = lane - 3u * bcol;   // column `lane` = basis bcol, channel ccol
+                // The member loop is what the emission issues most of (3.2 members per row), so it is kept to one LDS read
+                // and three FMAs whose gradient operand is the scalar register v_readlane wrote: every lane keeps all three
+                // channels' sums and picks its own once per row (a per-member select costs three moves and two selects),
+                // and lanes past the row read a clamped word instead of being masked off around the read.
+                const float *srow = stage + (bcol < (uint32_t)NB ? bcol : (uint32_t)NB - 1u);
 #pragma unroll
                 for (int w = 0; w < kRowWindow; ++w) {
                     while (hm[w] != 0ull) {
                         const int src = __builtin_ctzll(hm[w]);
                         const uint32_t cell = readlane(hc[w], src);
-                        float v = 0.0f;
+                        float vr = 0.0f, vg = 0.0f, vb = 0.0f;
 #pragma unroll
                         for (int u = w; u < kRowWindow; ++u) {
                             unsigned long long group = hm[u] & ballot(hc[u] == cell);   // step u's lit lanes in this cell
                             hm[u] &= ~group;
                             while (group != 0ull) {
                                 const int m = __builtin_ctzll(group);
-                                group &= group - 1ull;
-                                const float gr = readlane_f(hr[u], m), gg = readlane_f(hg[u], m), gb = readlane_f(hb[u], m);
-                                const float gc = ccol == 0u ? gr : (ccol == 1u ? gg : gb);
-                                if (lane < (uint32_t)NC) v += stage[(uint32_t)m * NB + bcol] * gc;
+                                group &= ~(1ull << m);
+                                const float x = srow[(uint32_t)m * NB];
+                                vr = fma_(x, readlane_f(hr[u], m), vr);
+                                vg = fma_(x, readlane_f(hg[u], m), vg);
+                                vb = fma_(x, readlane_f(hb[u], m), vb);
                             }
                         }
+                        const float v = ccol == 0u ? vr : (ccol == 1u ? vg : vb);
                         if (lane < (uint32_t)NC && v != 0.0f) grad_add(p.attr_grad + (size_t)cell * p.attr_pitch + lane, v);
                     }
                 }
