@@ -331,11 +331,13 @@ def main():
 
 
 def run_train_loop(args, W, env):
-    """--workload train-loop: examples/train_loop.py (one GPU; the loop is the reference's, which has no data-parallel
-    mode).  One JSON line in the same shape as the others; `value` is iterations per second."""
-    if env["world"] != 1 or not env["on_gpu"]:
-        raise SystemExit("--workload train-loop runs on one GPU")
-    torch, dev = env["torch"], env["dev"]
+    """--workload train-loop: examples/train_loop.py.  One JSON line in the same shape as the others; `value` is iterations
+    per second.  ``--gpus N``: BASELINE config 4 as the north star states it -- the same loop on every rank, every batch's
+    rays split over the ranks (radfoam.BatchFetcher(rank=, world_size=)), gradients exchanged inside trace_backward
+    (radfoam_amd.dist.DataParallelPipeline), identical Adam step and rebuild on every rank: strong scaling of the batch."""
+    if not env["on_gpu"]:
+        raise SystemExit("--workload train-loop needs GPUs (tests/test_dist_training.py covers the step on CPU ranks)")
+    torch, dist, dev, world, rank = env["torch"], env["dist"], env["dev"], env["world"], env["rank"]
     from examples import train_loop
     from radfoam_amd import foam
 
@@ -346,17 +348,28 @@ def run_train_loop(args, W, env):
         return sorted_pts.cpu().numpy(), off.cpu().numpy(), adj.cpu().numpy()
 
     t0 = time.time()
+    if world > 1 and rank != 0:
+        dist.barrier()      # rank 0 triangulates (or loads) first, so the cache is written once
     fm = foam.make_synthetic_foam(W["points"], W["sh"], W["seed"], cache_dir=foam.default_cache_dir(),
                                   triangulate=gpu_triangulation)
+    if world > 1 and rank == 0:
+        dist.barrier()
     its, detail = train_loop.run(args, env, fm, sh_degree=W["sh"], iterations=args.steps, rays_per_batch=W["rays"],
                                  width=W["width"], height=W["height"], densify_at=max(1, args.steps // 2))
+    if world > 1:           # the slowest rank's clock (the ranks meet in every step's exchange: they agree to a step)
+        t = torch.tensor([detail["wall_seconds"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        its = args.steps / float(t.item())
+        detail["wall_seconds_slowest_rank"] = round(float(t.item()), 2)
+        if rank != 0:
+            return None
     detail["setup_and_loop_seconds"] = round(time.time() - t0, 1)
     per = detail["ms_per_iteration"]
     tracer = per["tracer_forward"] + per["tracer_backward"]
     detail["tracer_share_of_wall"] = round(tracer / detail["wall_ms_per_iteration"], 4)
     return {
         "metric": f"training iterations/s, {W['label']}",
-        "value": round(its, 3), "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": 0,
+        "value": round(its, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": 0,
         "ms_per_step": detail["wall_ms_per_iteration"], "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
@@ -366,7 +379,11 @@ def run_train_loop(args, W, env):
                         f"update_triangulation on the schedule of train.py:243-248, one densification at iteration "
                         f"{max(1, args.steps // 2)} (collect_error_map + prune_and_densify + full rebuild)",
             "num_points": W["points"], "sh_degree": W["sh"], "rays_per_step": W["rays"],
-            "weight_threshold": 1e-3, "max_intersections": 1024, "parallelism": "1 GPU",
+            "weight_threshold": 1e-3, "max_intersections": 1024,
+            "parallelism": "1 GPU" if world == 1 else
+                           f"data parallel over {world} GPUs: every batch's rays split by index ({W['rays'] // world} per rank), "
+                           "foam and optimiser replicated, gradients averaged inside trace_backward (one all-reduce of the "
+                           "flat [points_grad | attr_grad] buffer), every rank rebuilds its own identical triangulation",
         },
         "mrays_per_second_through_the_loop": round(its * W["rays"] / 1e6, 2),
         "detail": detail,

@@ -286,6 +286,14 @@ int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_
 int rf_fetch_batch(const void *data, uint64_t num_elements, uint32_t stride_bytes, uint32_t batch_index,
                    uint32_t batch_size, int shuffle, void *out, void *stream);
 
+/* One rank's share of a batch (data-parallel training, BASELINE config 4: "rays row-sharded across 8 GPUs"; the reference is
+ * single-GPU, so this has no counterpart beyond batch_fetcher.cpp:60-70's sequence): out[j] = data[index(first_sequence + j)]
+ * for j < count, with the index rule of rf_fetch_batch.  Rank r of W takes first_sequence = batch_index * batch_size +
+ * r * batch_size / W and count = batch_size / W: the ranks' shares concatenated in rank order are the batch the reference's
+ * single fetcher returns, so W ranks see exactly the rays one process would. */
+int rf_fetch_batch_range(const void *data, uint64_t num_elements, uint32_t stride_bytes, uint64_t first_sequence,
+                         uint32_t count, int shuffle, void *out, void *stream);
+
 /* Coherent processing order for a flat batch of rays: sorts the ray indices by (entry cell, Morton
  * code of the direction on a 2^16 x 2^16 octahedral grid), so that 64 / 256 consecutive entries are
  * a compact patch of directions from one origin.  rays is float[num_rays][6] (direction need not be

@@ -88,6 +88,7 @@ SYMBOLS = {
     "rf_nearest_point_tree": (_INT, [_P, _U32, _P, _P, _U32, _P, _P]),
     "rf_farthest_neighbor": (_INT, [_P, _U32, _P, _P, _P, _P, _P]),
     "rf_fetch_batch": (_INT, [_P, C.c_uint64, _U32, _U32, _U32, _INT, _P, _P]),
+    "rf_fetch_batch_range": (_INT, [_P, C.c_uint64, _U32, C.c_uint64, _U32, _INT, _P, _P]),
     "rf_ray_order_workspace_bytes": (C.c_size_t, [_U32]),
     "rf_build_ray_order": (_INT, [_P, _P, _U32, _P, _P, C.c_size_t, _P]),
     "rf_adjacency_workspace_bytes": (C.c_size_t, [_U32]),

@@ -383,22 +383,34 @@ int rf_farthest_neighbor(const float *points, uint32_t num_points, const uint32_
 }
 
 
-int rf_fetch_batch(const void *data, uint64_t num_elements, uint32_t stride_bytes, uint32_t batch_index,
-                   uint32_t batch_size, int shuffle, void *out, void *stream) {
+static int fetch_batch_launch(const char *who, const void *data, uint64_t num_elements, uint32_t stride_bytes,
+                              uint64_t first, uint32_t count, int shuffle, void *out, void *stream) {
     g_err[0] = 0;
-    if (batch_size == 0) return RF_OK;
-    if (!data || !out) return fail(RF_ERR_INVALID_ARGUMENT, "rf_fetch_batch: null pointer");
-    if (num_elements == 0 || num_elements > 0xFFFFFFFFull)
-        return fail(RF_ERR_INVALID_ARGUMENT, num_elements ? "Too many elements" : "rf_fetch_batch: no elements");
+    if (count == 0) return RF_OK;
+    if (!data || !out) return fail(RF_ERR_INVALID_ARGUMENT, "%s: null pointer", who);
+    if (num_elements == 0) return fail(RF_ERR_INVALID_ARGUMENT, "%s: no elements", who);
+    if (num_elements > 0xFFFFFFFFull) return fail(RF_ERR_INVALID_ARGUMENT, "Too many elements");
     if (stride_bytes == 0 || (stride_bytes & 3u))
-        return fail(RF_ERR_INVALID_ARGUMENT, "rf_fetch_batch: stride must be a positive multiple of 4 bytes");
+        return fail(RF_ERR_INVALID_ARGUMENT, "%s: stride must be a positive multiple of 4 bytes", who);
     const uint32_t words = stride_bytes / 4u;
-    const uint64_t total = (uint64_t)batch_size * words;
-    if (total > 0xFFFFFFFFull * 256ull) return fail(RF_ERR_INVALID_ARGUMENT, "rf_fetch_batch: batch too large");
+    const uint64_t total = (uint64_t)count * words;
+    if (total > 0xFFFFFFFFull * 256ull) return fail(RF_ERR_INVALID_ARGUMENT, "%s: batch too large", who);
     hipLaunchKernelGGL(fetch_batch_kernel, dim3((unsigned)((total + 255u) / 256u)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<const uint32_t *>(data), num_elements, words,
-                       (uint64_t)batch_index * (uint64_t)batch_size, batch_size, shuffle, static_cast<uint32_t *>(out));
-    return check_launch("rf_fetch_batch");
+                       first, count, shuffle, static_cast<uint32_t *>(out));
+    return check_launch(who);
+}
+
+int rf_fetch_batch(const void *data, uint64_t num_elements, uint32_t stride_bytes, uint32_t batch_index,
+                   uint32_t batch_size, int shuffle, void *out, void *stream) {
+    return fetch_batch_launch("rf_fetch_batch", data, num_elements, stride_bytes,
+                              (uint64_t)batch_index * (uint64_t)batch_size, batch_size, shuffle, out, stream);
+}
+
+int rf_fetch_batch_range(const void *data, uint64_t num_elements, uint32_t stride_bytes, uint64_t first_sequence,
+                         uint32_t count, int shuffle, void *out, void *stream) {
+    return fetch_batch_launch("rf_fetch_batch_range", data, num_elements, stride_bytes, first_sequence, count, shuffle,
+                              out, stream);
 }
 
 

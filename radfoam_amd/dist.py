@@ -311,10 +311,18 @@ class ShardedTracer:
         self.group = group
         self.bounds = None
         self.sparse = SparseGradExchange(group) if exchange == "sparse" else None
-        if self.sparse is None and hasattr(pipeline, "gradient_row_pitch") and self._world() > 1:
-            # the dense exchange all-reduces the flat buffer: padding columns (13 -> 16, 28 -> 32, 49 -> 64 floats per
-            # row) would be up to 29 % more xGMI bytes per step; the sparse exchange sends packed rows whatever the pitch
-            pipeline.gradient_row_pitch = "dense"
+        self._pitch_decided = False
+
+    def _decide_row_pitch(self):
+        """The dense exchange all-reduces the flat buffer: padding columns (13 -> 16, 28 -> 32, 49 -> 64 floats per row)
+        would be up to 29 % more xGMI bytes per step, so a multi-rank dense tracer asks the pipeline for dense rows; the
+        sparse exchange sends packed rows whatever the pitch.  Decided at the first backward, when the world size is
+        known for sure -- a tracer may be built before init_process_group."""
+        if self._pitch_decided or not dist.is_initialized():
+            return
+        self._pitch_decided = True
+        if self.sparse is None and hasattr(self.pipeline, "gradient_row_pitch") and self._world() > 1:
+            self.pipeline.gradient_row_pitch = "dense"
 
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -362,6 +370,7 @@ class ShardedTracer:
 
     def backward(self, points, attributes, adjacency, offsets, rays, start_point, rgba_local, grad_local,
                  depth_quantiles=None, depth_indices_local=None, depth_grad_local=None, **kw):
+        self._decide_row_pitch()
         res = self.pipeline.trace_backward(points, attributes, adjacency, offsets, self._shard(rays),
                                            self._shard(start_point), rgba_local, grad_local,
                                            self._shard(depth_quantiles), depth_indices_local, depth_grad_local, **kw)
@@ -370,3 +379,252 @@ class ShardedTracer:
         else:
             all_reduce_gradients(res, group=self.group)
         return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Data-parallel TRAINING (BASELINE config 4: "full train.py loop, rays row-sharded across 8xMI355X with RCCL grad
+# all-reduce").  The reference has no distributed mode at all; what follows lets its unmodified
+# RadFoamScene / TraceRays / train.py loop body run one process per GPU with identical parameters on every rank.
+
+
+def replica_checksums(tensors) -> torch.Tensor:
+    """One int64 per tensor: a position-weighted wrap-around sum of its 32-bit words (any dtype whose element size is a
+    multiple of 4 bytes; bools / bytes are widened).  Equal tensors give equal sums; a single differing word changes it."""
+    sums = []
+    for t in tensors:
+        t = t.detach().contiguous()
+        if t.element_size() % 4:
+            t = t.to(torch.int32)
+        w = t.view(torch.int32).reshape(-1).to(torch.int64)
+        k = torch.arange(w.numel(), device=w.device, dtype=torch.int64)
+        sums.append(((w + 0x9E3779B1) * (2 * k + 1)).sum() + w.numel())
+    return torch.stack(sums) if sums else torch.zeros(0, dtype=torch.int64)
+
+
+def assert_replicas_agree(named_tensors: dict, group=None):
+    """Raise unless every rank holds the same bits in every named tensor (parameters after an optimiser step, the
+    adjacency lists after a rebuild: the replicated foam must stay replicated or the ranks' gradients describe different
+    scenes).  One small all-gather of checksums.  Returns the checksums (int64 [len(named_tensors)])."""
+    names = list(named_tensors)
+    mine = replica_checksums([named_tensors[k] for k in names])
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return mine
+    world = dist.get_world_size(group)
+    shapes = torch.tensor([named_tensors[k].numel() for k in names], dtype=torch.int64, device=mine.device)
+    both = torch.cat([mine, shapes])
+    parts = [torch.empty_like(both) for _ in range(world)]
+    dist.all_gather(parts, both, group=group)
+    host = [p.cpu() for p in parts]
+    for r in range(1, world):
+        if not torch.equal(host[r], host[0]):
+            bad = [names[i % len(names)] for i in (host[r] != host[0]).nonzero().reshape(-1).tolist()]
+            raise RuntimeError(f"data-parallel replicas diverged: rank {r} differs from rank 0 in {sorted(set(bad))}")
+    return mine
+
+
+class DataParallelPipeline:
+    """A ``radfoam.Pipeline`` that keeps the ranks of a data-parallel job consistent: same methods, same arguments, same
+    returned dicts as the pipeline it wraps (pipeline_bindings.cpp:626-667), plus the exchanges one process per GPU needs.
+    The reference's ``TraceRays`` (radfoam_model/render.py:10-122) calls it like any pipeline, so its ``loss.backward()``
+    ends in gradients already combined over the ranks and an identical Adam step follows on every rank.
+
+    Two ways to divide a step's rays (``shard``; ``replicated_inputs()`` switches to "rows" for a block of calls):
+
+      "caller"  the caller hands every rank ITS share (``BatchFetcher(..., rank=, world_size=)``: the ranks' batches
+                concatenated are the batch one process would fetch).  Outputs are the share's; ``trace_backward``
+                exchanges the flat ``[points_grad | attr_grad]`` buffer and -- ``reduce="mean"`` -- divides by the world
+                size: train.py's losses are means over the batch (train.py:188-204), so the mean of the ranks'
+                gradients IS the gradient of the whole batch's loss.  ``contribution`` / ``point_error`` are per-point
+                SUMS over rays and are summed over ranks.
+      "rows"    every rank is handed the SAME rays (collect_error_map's views, evaluation renders, or a train.py whose
+                data loader was left alone): each rank traces its contiguous block of leading-dimension rows, forward
+                outputs are all-gathered, so every rank returns what a single process would -- bit for bit in rgba /
+                depth / num_intersections -- and the backward takes its block of the caller's full upstream gradient and
+                SUMS over ranks (the shares are disjoint parts of one loss).  No rank-dependent value reaches the
+                caller: loss, statistics and whatever the scene derives from them stay identical on every rank.
+
+    ``exchange``: "dense" = one SUM all-reduce of the flat buffer (RCCL: reduce-scatter + all-gather over the xGMI mesh);
+    "sparse" = SparseGradExchange (packed non-zero rows, added in rank order); "auto" = sparse for image-shaped rays
+    (a frame's row blocks touch nearly disjoint cells), dense for flat batches (a shuffled batch touches everything).
+    Either way every rank ends with the SAME bits, which the replicated optimiser needs.  The row pitch of the gradient
+    accumulator is left to the pipeline (rows on 64-byte lines: 29 % more bytes on the wire than dense rows at SH 3, but
+    the all-lit backward is 2x slower without them).
+    """
+
+    def __init__(self, pipeline, group=None, shard: str = "caller", reduce: str = "mean", exchange: str = "auto"):
+        if shard not in ("caller", "rows"):
+            raise ValueError("shard must be 'caller' or 'rows'")
+        if reduce not in ("mean", "sum"):
+            raise ValueError("reduce must be 'mean' or 'sum'")
+        if exchange not in ("auto", "dense", "sparse"):
+            raise ValueError("exchange must be 'auto', 'dense' or 'sparse'")
+        self.inner = pipeline
+        self.group = group
+        self.shard = shard
+        self.reduce = reduce
+        self.exchange = exchange
+        self._sparse = SparseGradExchange(group)
+        #: what the last trace_backward did: {"exchange": "dense" | "sparse" | "none", "world": W, "rows": [..] | None}
+        self.last_exchange = None
+
+    # everything that is not a trace call (attribute_dim, knobs such as backward_mode, invalidate, ...) is the inner
+    # pipeline's; knobs set on the wrapper land on the inner pipeline too
+    def __getattr__(self, name):
+        return getattr(self.__dict__["inner"], name)
+
+    def __setattr__(self, name, value):
+        own = name.startswith("_") or name in self.__dict__ or hasattr(type(self), name) or callable(value) or \
+            "inner" not in self.__dict__ or not hasattr(self.__dict__["inner"], name)
+        if own:     # the wrapper's own state, and methods patched onto it (a profiler timing trace_forward)
+            object.__setattr__(self, name, value)
+        else:       # a knob of the wrapped pipeline (backward_mode, record_trail, tile_order_mode, ...)
+            setattr(self.__dict__["inner"], name, value)
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _rank(self):
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    class _Replicated:
+        def __init__(self, outer):
+            self.outer = outer
+
+        def __enter__(self):
+            self.was = self.outer.shard
+            self.outer.shard = "rows"
+            return self.outer
+
+        def __exit__(self, *exc):
+            self.outer.shard = self.was
+            return False
+
+    def replicated_inputs(self):
+        """``with pipeline.replicated_inputs():`` -- the calls inside receive the same rays on every rank ("rows")."""
+        return DataParallelPipeline._Replicated(self)
+
+    # -- forward --------------------------------------------------------------------------------------------------------
+    def trace_forward(self, points, attributes, point_adjacency, point_adjacency_offsets, rays, start_point,
+                      depth_quantiles=None, weight_threshold=None, max_intersections=None, return_contribution=False,
+                      **extra):
+        world = self._world()
+        kw = dict(depth_quantiles=depth_quantiles, weight_threshold=weight_threshold,
+                  max_intersections=max_intersections, return_contribution=return_contribution, **extra)
+        if world == 1:
+            return self.inner.trace_forward(points, attributes, point_adjacency, point_adjacency_offsets, rays,
+                                            start_point, **kw)
+        if self.shard == "caller":
+            out = self.inner.trace_forward(points, attributes, point_adjacency, point_adjacency_offsets, rays,
+                                           start_point, **kw)
+            if return_contribution:
+                all_reduce_statistic(out["contribution"], group=self.group)
+            return out
+        # "rows": the same rays everywhere; this rank traces its block of leading rows, everyone gets everything
+        rank = self._rank()
+        lead = rays.shape[:-1]
+        if len(lead) == 0:
+            raise RuntimeError("rays must have a batch dimension")
+        start_b = torch.broadcast_to(start_point, lead)
+        cut = lambda t: None if t is None else shard_rows(t, rank, world)
+        kw["depth_quantiles"] = cut(depth_quantiles)
+        local = self.inner.trace_forward(points, attributes, point_adjacency, point_adjacency_offsets, cut(rays),
+                                         cut(start_b), **kw)
+        out = {}
+        for key in ("rgba", "depth", "depth_indices", "num_intersections"):
+            if key in local:
+                t = local[key]
+                view32 = t.dtype == torch.uint32            # collectives on uint32 are thin: move the words as int32
+                g = gather_rows(t.view(torch.int32) if view32 else t, lead[0], group=self.group)
+                out[key] = g.view(torch.uint32) if view32 else g
+        if return_contribution:
+            out["contribution"] = all_reduce_statistic(local["contribution"], group=self.group)
+        return out
+
+    # -- backward -------------------------------------------------------------------------------------------------------
+    def _exchange(self, res, image_shaped):
+        world = self._world()
+        how = self.exchange if self.exchange != "auto" else ("sparse" if image_shaped else "dense")
+        rows = None
+        if how == "sparse":
+            self._sparse.reduce(res)           # (point_error summed inside)
+            rows = self._sparse.last_counts
+            if rows is None:
+                how = "dense"                  # the lists were not sparse: reduce() fell back to the all-reduce
+        else:
+            all_reduce_gradients(res, group=self.group)
+        self.last_exchange = {"exchange": how, "world": world, "rows": rows}
+
+    def trace_backward(self, points, attributes, point_adjacency, point_adjacency_offsets, rays, start_point, rgb_out,
+                       grad_in, depth_quantiles=None, depth_indices=None, depth_grad_in=None, ray_error=None,
+                       weight_threshold=None, max_intersections=None):
+        world = self._world()
+        if world == 1:
+            self.last_exchange = {"exchange": "none", "world": 1, "rows": None}
+            return self.inner.trace_backward(points, attributes, point_adjacency, point_adjacency_offsets, rays,
+                                             start_point, rgb_out, grad_in, depth_quantiles, depth_indices, depth_grad_in,
+                                             ray_error, weight_threshold, max_intersections)
+        rank = self._rank()
+        full_rays = rays
+        if self.shard == "rows":
+            lead = rays.shape[:-1]
+            start_b = torch.broadcast_to(start_point, lead)
+            cut = lambda t: None if t is None else shard_rows(t, rank, world)
+            # (this rank's rows of the gathered forward outputs are its own forward's outputs, bit for bit)
+            rays, start_point = cut(rays), cut(start_b)
+            rgb_out, grad_in = cut(rgb_out), cut(grad_in)
+            depth_quantiles, depth_indices, depth_grad_in = cut(depth_quantiles), cut(depth_indices), cut(depth_grad_in)
+            ray_error = None if ray_error is None else cut(torch.broadcast_to(ray_error, lead))
+        res = self.inner.trace_backward(points, attributes, point_adjacency, point_adjacency_offsets, rays, start_point,
+                                        rgb_out, grad_in, depth_quantiles, depth_indices, depth_grad_in, ray_error,
+                                        weight_threshold, max_intersections)
+        self._exchange(res, image_shaped=full_rays.dim() == 3)
+        if self.reduce == "mean" and self.shard == "caller":
+            scale = 1.0 / world
+            flat = res.get("flat_grad")
+            ag = res["attr_grad"]
+            if flat is not None and ag.dtype == flat.dtype and \
+                    ag.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr():
+                flat.mul_(scale)
+            else:
+                res["points_grad"].mul_(scale)
+                ag.mul_(scale)
+        if self.shard == "rows":
+            res["ray_grad"] = torch.zeros_like(full_rays)      # the reference never writes it (pipeline_bindings.cpp:455)
+        return res
+
+    def trace_benchmark(self, *args, **kwargs):
+        """The render path writes the caller's frame in place: every rank renders it whole (no exchange)."""
+        return self.inner.trace_benchmark(*args, **kwargs)
+
+
+_DATA_PARALLEL = {"on": False, "kw": {}}
+
+
+def enable_data_parallel(shard_batches: bool = True, **pipeline_kw):
+    """After ``init_process_group``: from now on ``radfoam.create_pipeline`` returns a DataParallelPipeline
+    (``pipeline_kw``: its ``group`` / ``shard`` / ``reduce`` / ``exchange``) and -- ``shard_batches`` -- every
+    ``radfoam.BatchFetcher(..., shuffle=True)`` serves this rank's share of the reference's index sequence.  That is all an
+    unmodified train.py needs to run one process per GPU: its scene calls create_pipeline (scene.py:59), its data loader
+    builds the shuffled fetchers (data_loader/__init__.py:113-127), its collect_error_map / test renders use sequential
+    fetchers, which stay whole -- wrap those calls in ``model.pipeline.replicated_inputs()``."""
+    from . import shims
+    if not dist.is_initialized():
+        raise RuntimeError("enable_data_parallel: call torch.distributed.init_process_group first")
+    group = pipeline_kw.get("group")
+    _DATA_PARALLEL["on"] = True
+    _DATA_PARALLEL["kw"] = dict(pipeline_kw)
+    shims.BatchFetcher.default_shard = (dist.get_rank(group), dist.get_world_size(group)) if shard_batches else None
+
+
+def disable_data_parallel():
+    from . import shims
+    _DATA_PARALLEL["on"] = False
+    _DATA_PARALLEL["kw"] = {}
+    shims.BatchFetcher.default_shard = None
+
+
+def wrap_pipeline(pipeline):
+    """What create_pipeline returns: the pipeline itself, or -- after enable_data_parallel() -- its data-parallel wrapper."""
+    if _DATA_PARALLEL["on"] and not isinstance(pipeline, DataParallelPipeline):
+        return DataParallelPipeline(pipeline, **_DATA_PARALLEL["kw"])
+    return pipeline

@@ -1036,4 +1036,5 @@ class Pipeline:
 
 def create_pipeline(sh_degree, attr_dtype="float32") -> Pipeline:
     """radfoam.create_pipeline (pipeline_bindings.cpp:587-590,669-672; pipeline.cu:776-805)."""
-    return Pipeline(sh_degree, attr_dtype)
+    from . import dist as _dist      # (after radfoam_amd.dist.enable_data_parallel(): the data-parallel wrapper)
+    return _dist.wrap_pipeline(Pipeline(sh_degree, attr_dtype))

@@ -231,10 +231,34 @@ class BatchFetcher:
 
     device_resident_limit = 64 << 30
 
-    def __init__(self, data: torch.Tensor, batch_size: int, shuffle: bool):
+    #: (rank, world_size) every ``shuffle=True`` fetcher constructed WITHOUT explicit ``rank`` / ``world_size`` serves;
+    #: None = the whole batch (the reference's behaviour).  radfoam_amd.dist.enable_data_parallel() sets it so that the
+    #: reference's unmodified data_loader (``get_iter``, data_loader/__init__.py:113-127) hands every rank its share of
+    #: the training batches; sequential fetchers (``shuffle=False``: collect_error_map's views, test renders) are never
+    #: sharded by default.
+    default_shard = None
+
+    def __init__(self, data: torch.Tensor, batch_size: int, shuffle: bool, rank: int | None = None,
+                 world_size: int | None = None):
+        """``rank`` / ``world_size`` (keyword extensions; the reference is single-GPU): serve elements
+        [rank * batch_size / world_size, (rank + 1) * batch_size / world_size) of every batch of the reference's index
+        sequence -- the ranks' shares, concatenated in rank order, ARE the batch one process would fetch, so a
+        data-parallel run sees the same rays as the single-process run (radfoam_amd/dist.py)."""
         self.batch_size = int(batch_size)
         self.shuffle = bool(shuffle)
         self.batch_idx = 0
+        if rank is None and world_size is None and self.shuffle and BatchFetcher.default_shard is not None:
+            rank, world_size = BatchFetcher.default_shard
+        if (rank is None) != (world_size is None):
+            raise RuntimeError("BatchFetcher: rank and world_size go together")
+        self.rank, self.world_size = (0, 1) if rank is None else (int(rank), int(world_size))
+        if self.world_size < 1 or not (0 <= self.rank < self.world_size):
+            raise RuntimeError("BatchFetcher: invalid rank / world_size")
+        if self.batch_size % self.world_size:
+            # equal shares only: the mean of the ranks' mean losses is then the batch's mean loss (train.py:188-204)
+            raise RuntimeError(f"BatchFetcher: batch_size {self.batch_size} is not a multiple of world_size {self.world_size}")
+        #: elements next() returns: batch_size / world_size
+        self.local_batch_size = self.batch_size // self.world_size
         self.device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
         if data.size(0) > 0xFFFFFFFF:
             raise RuntimeError("Too many elements")            # batch_fetcher.cpp:49
@@ -260,9 +284,13 @@ class BatchFetcher:
             self.device = data.device
         self.data = data
 
+    def _first(self) -> int:
+        """Position in the reference's sequence of the first element next() returns."""
+        return self.batch_idx * self.batch_size + self.rank * self.local_batch_size
+
     def _indices(self) -> np.ndarray:
         n = self.data.size(0)
-        base = np.arange(self.batch_size, dtype=np.uint64) + np.uint64(self.batch_idx) * np.uint64(self.batch_size)
+        base = np.arange(self.local_batch_size, dtype=np.uint64) + np.uint64(self._first())
         if not self.shuffle:
             return (base % np.uint64(n)).astype(np.int64)
         seed = (base & np.uint64(0xFFFFFFFF)).astype(np.uint32)
@@ -276,11 +304,14 @@ class BatchFetcher:
             import ctypes as C
 
             from . import _lib
-            out = torch.empty((self.batch_size,) + tuple(self.data.shape[1:]), dtype=self.data.dtype, device=self.device)
+            out = torch.empty((self.local_batch_size,) + tuple(self.data.shape[1:]), dtype=self.data.dtype,
+                              device=self.device)
             with torch.cuda.device(self.device):
-                rc = _lib.load().rf_fetch_batch(
-                    C.c_void_p(self.data.data_ptr()), self.data.size(0), self._row_bytes, self.batch_idx & 0xFFFFFFFF,
-                    self.batch_size, int(self.shuffle), C.c_void_p(out.data_ptr()),
+                # (batch_idx wraps at 2^32 like the reference's uint32 counter; the sequence position is 64-bit)
+                first = (self.batch_idx & 0xFFFFFFFF) * self.batch_size + self.rank * self.local_batch_size
+                rc = _lib.load().rf_fetch_batch_range(
+                    C.c_void_p(self.data.data_ptr()), self.data.size(0), self._row_bytes, first,
+                    self.local_batch_size, int(self.shuffle), C.c_void_p(out.data_ptr()),
                     C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
             _lib.check(rc)
             self.batch_idx += 1

@@ -283,6 +283,7 @@ def test_batch_fetcher_on_the_device_follows_the_references_index_sequence(shuff
         assert f._native and f.data.is_cuda
         ref = shims.BatchFetcher.__new__(shims.BatchFetcher)      # the numpy index path of the same class
         ref.data, ref.batch_size, ref.shuffle, ref.batch_idx = data, bs, shuffle, 0
+        ref.rank, ref.world_size, ref.local_batch_size = 0, 1, bs
         for b in range(3):
             want = data[torch.from_numpy(ref._indices())]
             ref.batch_idx += 1
@@ -299,3 +300,10 @@ def test_batch_fetcher_on_the_device_follows_the_references_index_sequence(shuff
     ref.data, ref.batch_idx = data, (1 << 32) // bs + 7
     f.batch_idx = ref.batch_idx
     assert torch.equal(f.next().cpu(), data[torch.from_numpy(ref._indices())])
+    # data-parallel training: the ranks' shares (rf_fetch_batch_range), concatenated in rank order, are the batch
+    for world in (2, 8):
+        whole = radfoam.BatchFetcher(data, bs, shuffle)
+        parts = [radfoam.BatchFetcher(data, bs, shuffle, rank=r, world_size=world) for r in range(world)]
+        for b in range(2):
+            got = torch.cat([p.next() for p in parts])
+            assert got.shape[0] == bs and torch.equal(got, whole.next()), (world, b)
