@@ -99,6 +99,11 @@ typedef struct rf_launch_opts {
                               /*   batches, launches of at most 1024 blocks).  0..2, 4, 5 find the exit by a tournament on   */
                               /*   cross-multiplied products with a certificate and divide only the winner (cells whose      */
                               /*   certificate fails -- two exits within 3 floats -- are scanned again by the dividing scan); */
+                              /*   the certificate's proof needs the compared quotients to be NORMAL floats (it is exact     */
+                              /*   for any inputs whose exit distances are not subnormal: nonzero coordinates of magnitude   */
+                              /*   >= 2^-40 suffice), and the library does not rely on the caller for that: a cell whose      */
+                              /*   winning quotient is zero or subnormal goes to the dividing scan as well (fail-safe),      */
+                              /*   so the result is the reference's for EVERY input the reference itself defines;            */
                               /*   3 = every face of every cell divided, as the reference writes it: the independent         */
                               /*   instance the others are tested against, 40 % slower.  rf_trace_benchmark honours 3;       */
                               /*   rf_trace_backward accepts and ignores the field (a trail replays under any mode).         */

@@ -254,9 +254,11 @@ struct __attribute__((aligned(8))) GeoZ {
 //            (D - 1.5) ulp(p) >= 2.5 * 2^-24 relative; the exact quotients num_a/dp_a and num_b/dp_b differ by the same
 //            relative amount (divide both products by dp_a dp_b), which is more than one ulp of a quotient (at most
 //            2^-23 relative), and two reals more than an ulp apart round to different floats in their own order.
-//            (Zero and subnormal products: same argument with absolute spacings, 2^-149.  Opposite signs: D >= 2^23.
-//            Assumes nonzero point / origin coordinates of magnitude >= 2^-40, so that a nonzero num is >= 2^-87 and no
-//            QUOTIENT is subnormal.)  A pairwise tournament over such comparisons (the nearer face of a pair, then
+//            (Zero and subnormal products: same argument with absolute spacings, 2^-149 -- relatively coarser, so the
+//            bound holds a fortiori.  Opposite signs: D >= 2^23.  The one assumption: the two QUOTIENTS are normal floats,
+//            whose ulp is at most 2^-23 relative; it is not left to the caller (include/radfoam_hip.h states it) but
+//            checked: scan_end sends a cell whose winning quotient has a zero exponent field to the dividing scan.)
+//            A pairwise tournament over such comparisons (the nearer face of a pair, then
 //            against the running best; earlier faces win ties) therefore returns the reference's face whenever NO
 //            comparison it made had D <= kTieUlps = 3;
 //   certify  the scan keeps the minimum D over all its comparisons (v_sad_u32 + v_min3_u32: three instructions per pair
@@ -399,7 +401,12 @@ __device__ __forceinline__ ScanResult scan_end(const ScanState &S, bool &contest
     // a quotient that overflows is no exit for the reference either (t < inf fails); nothing can be nearer: the tournament's
     // winner has the smallest exact quotient
     if (!(r.t1 < __builtin_inff())) r.k = kNone;
-    contested = S.tie <= kTieUlps;
+    // Fail-safe of the certificate's one assumption ("no quotient is subnormal", above): with a zero or subnormal winning
+    // quotient two exits more than an ulp-of-a-normal apart may still round to the SAME float, where the reference keeps the
+    // first and the products order them strictly.  Any comparison between two such faces ends with a winner whose quotient is
+    // at most theirs in magnitude class, so looking at the winner's exponent field is enough: zero => the dividing scan decides.
+    const bool tiny = found && (__builtin_bit_cast(uint32_t, r.t1) & 0x7F800000u) == 0u;
+    contested = (S.tie <= kTieUlps) | tiny;
     return r;
 }
 
@@ -2658,12 +2665,16 @@ __global__ __launch_bounds__(256) void prepare_foam_kernel(
                 const float qx = points[3 * (size_t)q], qy = points[3 * (size_t)q + 1], qz = points[3 * (size_t)q + 2];
                 d = pack_diff(qx - px, qy - py, qz - pz);
             }
-            if (real) {
+            {
+                // (a padding entry keeps the link of the face it copies: it never wins a scan -- see "the face scan" --
+                // but should rounding ever let one, the ray crosses into the neighbour that face leads to instead of
+                // following an all-zero link into cell 0)
                 const uint32_t qb = poff[q];
                 lk.nbr = q;
                 lk.first = qb;
                 lk.count = poff[q + 1] - qb;
-            } else {
+            }
+            if (!real) {
                 uint16_t hx, hy, hz;
                 pad_offset((uint16_t)(d.x & 0xFFFFu), (uint16_t)(d.x >> 16), (uint16_t)(d.y & 0xFFFFu), j & 3u, hx, hy, hz);
                 d = make_uint2((uint32_t)hx | ((uint32_t)hy << 16), (uint32_t)hz);
@@ -2674,7 +2685,7 @@ __global__ __launch_bounds__(256) void prepare_foam_kernel(
         g[4] = (uint16_t)(d.x >> 16);
         g[8] = (uint16_t)(d.y & 0xFFFFu);
         link[f] = lk;
-        nbr[f] = real ? lk.nbr : kNone;
+        nbr[f] = real ? lk.nbr : kNone;     // (kNone is how the geometry-only repack recognises a padding entry)
     }
 }
 

@@ -1109,3 +1109,57 @@ def test_writes_autograd_cannot_see_need_cache_foam_off_or_invalidate(foam_facto
     assert same(pipe.trace_forward(p, a, adj, off, r, s), ref0)     # documented: the packed copy of the old points
     pipe.invalidate()
     check_moved(pipe)
+
+
+@pytest.mark.parametrize("forward_mode", [1, 2, 3, 5])
+def test_subnormal_exit_distances_and_underflowing_foams(forward_mode):
+    """the certificate's proof assumes normal quotients; the kernels do not leave that to the caller
+    (scan_end's fail-safe: a winning quotient with a zero exponent field goes to the dividing scan).  Rays that start within
+    a few subnormals of a bisector -- where, without the fail-safe, the filtered evaluation picks other exits than the
+    reference (tests/test_oracle.py shows it on the CPU mirror) -- and whole foams scaled by 2^-12 / 2^-17 / 2^-60 (fp16
+    offsets normal / subnormal with heavy ties / all underflown to zero): every scheduling mode equals the oracle's LITERAL
+    reference scan bit for bit."""
+    from radfoam_amd import foam
+    from tests.test_oracle import _bisectors_through_the_origin
+
+    pts, adj, off = _bisectors_through_the_origin()
+    att = np.zeros((8, 4), dtype=np.float32)
+    att[:, :3] = 0.3
+    att[:, 3] = 2.0
+    rng = np.random.default_rng(3)
+    n = 20480                      # > reorder_min_rays: the flat batch takes the sorted order and (mode 5) the cell table
+    rays = np.zeros((n, 6), dtype=np.float32)
+    rays[:, 0] = -(rng.integers(1, 2000, n).astype(np.uint32).view(np.float32))
+    rays[: n // 2, 0] = -(rng.uniform(1.0, 2.0, n // 2) * 2.0 ** rng.integers(-140, -120, n // 2)).astype(np.float32)
+    rays[:, 1:3] = rng.uniform(-0.05, 0.05, (n, 2)).astype(np.float32)
+    d = np.stack([np.ones(n), rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n)], axis=1)
+    rays[:, 3:] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    start = np.zeros(n, dtype=np.uint32)
+    fm = {"points": pts, "attributes": att, "point_adjacency": adj, "point_adjacency_offsets": off}
+    want = O.trace_forward(0, pts, att, adj, off, rays, start)
+    pipe = _pipeline(0)
+    pipe.forward_mode = forward_mode
+    got, _ = _run_forward(pipe, fm, rays, start)
+    np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), want["rgba"].view(np.uint32))
+    np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32).reshape(-1), want["num_intersections"].reshape(-1))
+    assert float(want["rgba"][:, 3].max()) > 0
+
+    base = foam.make_synthetic_foam(3000, 1, 2)
+    cam = foam.default_camera(96, 64)
+    r0 = foam.camera_rays(cam)
+    pipe = _pipeline(1)
+    pipe.forward_mode = forward_mode
+    for e in (-12, -17, -60):
+        s = np.float32(2.0 ** e)
+        fs = dict(base)
+        fs["points"] = base["points"] * s
+        a = base["attributes"].copy()
+        a[:, -1] = np.minimum(a[:, -1] / s, np.float32(3e38))
+        fs["attributes"] = a
+        r = r0.copy()
+        r[..., :3] *= s
+        st = np.uint32(foam.nearest_point(base["points"], cam["position"]))
+        want = O.trace_forward(1, fs["points"], a, fs["point_adjacency"], fs["point_adjacency_offsets"], r, st)
+        got, _ = _run_forward(pipe, fs, r, st)
+        np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), want["rgba"].view(np.uint32), err_msg=str(e))
+        np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), want["num_intersections"], err_msg=str(e))

@@ -392,3 +392,99 @@ def test_certificate_on_adversarial_pairs_of_quotients():
     assert violations == 0, violations
     assert needed > 100_000, needed                     # below the threshold the products alone do get it wrong
     assert loose > 1000, loose                          # ... and two floats of distance are not enough
+
+
+def test_certificate_needs_normal_quotients_and_the_fail_safe_catches_the_rest():
+    """the certificate's proof assumes the compared quotients are NORMAL floats.  With subnormal
+    quotients it does fail -- two exits a few percent apart round to the same subnormal float, the reference keeps the first,
+    the products order them strictly (D >= 4) -- and the kernels' fail-safe (scan_end: a winning quotient with a zero
+    exponent field sends the cell to the dividing scan; mirrored by the oracle's filtered mode) catches every such pair:
+    among pairs certified at D >= 4, every wrong order or tie has min(|qa|, |qb|) below 2^-126."""
+    rng = np.random.default_rng(7)
+    n = 2_000_000
+    wrong_total = wrong_caught = 0
+    with np.errstate(over="ignore", under="ignore"):
+        for rnd in range(4):
+            # numerators tiny (a ray origin within 1e-40 of a bisector through the coordinate origin), denominators ordinary
+            na = (rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-149, -120, n)).astype(np.float32)
+            da = (rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-3, 4, n)).astype(np.float32)
+            db = (rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-3, 4, n)).astype(np.float32)
+            rel = 1.0 + rng.uniform(-0.3, 0.3, n)
+            nb = (na.astype(np.float64) / da.astype(np.float64) * db.astype(np.float64) * rel).astype(np.float32)
+            ok = (na != 0) & (nb != 0)
+            na, da, db, nb = na[ok], da[ok], db[ok], nb[ok]
+            p1 = (na.astype(np.float64) * db.astype(np.float64)).astype(np.float32)
+            p2 = (nb.astype(np.float64) * da.astype(np.float64)).astype(np.float32)
+            dist = np.abs(p1.view(np.uint32).astype(np.int64) - p2.view(np.uint32).astype(np.int64))
+            qa, qb = na / da, nb / db
+            sure = dist >= 4
+            wrong = sure & (((p1 < p2) != (qa < qb)) | (qa == qb))
+            tiny = (np.minimum(np.abs(qa), np.abs(qb)).view(np.uint32) & 0x7F800000) == 0
+            wrong_total += int(wrong.sum())
+            wrong_caught += int((wrong & tiny).sum())
+    assert wrong_total > 1000, wrong_total          # the assumption is needed ...
+    assert wrong_caught == wrong_total              # ... and a zero exponent field of the smaller quotient finds every case
+
+
+def _bisectors_through_the_origin(shift=0.0):
+    """A hand-built cell whose exits are at SUBNORMAL distances: the cell's point at (-1/2, 0, 0) (+ shift in x), neighbours
+    mirrored through planes that pass within 1e-40 of the ray origin."""
+    # cell 0 in the middle, six neighbours; bisector of 0 and 1 is the plane x = 0 exactly (points -a and +a)
+    pts = np.array([[-0.5, 0.0, 0.0], [0.5, 0.0, 0.0], [-0.5, 1.0, 0.0], [-0.5, -1.0, 0.0], [-0.5, 0.0, 1.0],
+                    [-0.5, 0.0, -1.0], [-1.5, 0.0, 0.0], [0.5, 0.25, 0.0]], dtype=np.float32)
+    pts[:, 0] += np.float32(shift)
+    adj, off = [], [0]
+    nbrs = {0: [1, 2, 3, 4, 5, 6, 7], 1: [0, 7], 2: [0], 3: [0], 4: [0], 5: [0], 6: [0], 7: [0, 1]}
+    for i in range(8):
+        adj += nbrs[i]
+        off.append(len(adj))
+    return pts, np.array(adj, dtype=np.uint32), np.array(off, dtype=np.uint32)
+
+
+def test_filtered_evaluation_with_subnormal_exit_distances():
+    """Rays that start within a few subnormals of a bisector (t = 1e-41 .. 1e-38 to the first exit) and foams scaled down
+    until their fp16 offsets and exit distances underflow: the filtered evaluation (with its fail-safe) equals the
+    reference's loop bit for bit, and the fail-safe does fire."""
+    from oracle import oracle as O
+    pts, adj, off = _bisectors_through_the_origin()
+    att = np.zeros((8, 4), dtype=np.float32)
+    att[:, :3] = 0.3
+    att[:, 3] = 2.0
+    rng = np.random.default_rng(3)
+    n = 4096
+    rays = np.zeros((n, 6), dtype=np.float32)
+    # origins at subnormal / tiny negative x (inside cell 0, a hair from the plane x = 0), directions mostly +x
+    rays[:, 0] = -(rng.integers(1, 2000, n).astype(np.uint32).view(np.float32))       # -k * 2^-149
+    rays[: n // 2, 0] = -(rng.uniform(1.0, 2.0, n // 2) * 2.0 ** rng.integers(-140, -120, n // 2)).astype(np.float32)
+    rays[:, 1:3] = rng.uniform(-0.05, 0.05, (n, 2)).astype(np.float32)
+    d = np.stack([np.ones(n), rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n)], axis=1)
+    rays[:, 3:] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    start = np.zeros(n, dtype=np.uint32)
+    want = O.trace_forward(0, pts, att, adj, off, rays, start)
+    with O.scan_mode("filtered") as mode:
+        got = O.trace_forward(0, pts, att, adj, off, rays, start)
+        fired = mode.contested
+    assert np.array_equal(got["rgba"].view(np.uint32), want["rgba"].view(np.uint32))
+    assert np.array_equal(got["num_intersections"], want["num_intersections"])
+    assert fired > 0
+    assert float(want["rgba"][:, 3].max()) > 0          # the rays do cross into the neighbour and composite there
+    # whole foams scaled down: 2^-12 (fp16 offsets still normal), 2^-17 (subnormal fp16 offsets: heavy ties), 2^-60 (every
+    # offset underflows to zero: no exits anywhere, as in the reference)
+    from radfoam_amd import foam
+    fm = foam.make_synthetic_foam(3000, 1, 2)
+    cam = foam.default_camera(48, 32)
+    r0 = foam.camera_rays(cam).reshape(-1, 6)
+    for e in (-12, -17, -60):
+        s = np.float32(2.0 ** e)
+        p = fm["points"] * s
+        r = r0.copy()
+        r[:, :3] *= s
+        st = np.full(r.shape[0], foam.nearest_point(fm["points"], cam["position"]), dtype=np.uint32)
+        a = fm["attributes"].copy()
+        a[:, -1] = np.minimum(a[:, -1] / s, np.float32(3e38))                         # optical depths as before the scaling
+        args = (1, p, a, fm["point_adjacency"], fm["point_adjacency_offsets"], r, st)
+        want = O.trace_forward(*args)
+        with O.scan_mode("filtered"):
+            got = O.trace_forward(*args)
+        assert np.array_equal(got["rgba"].view(np.uint32), want["rgba"].view(np.uint32)), e
+        assert np.array_equal(got["num_intersections"], want["num_intersections"]), e
