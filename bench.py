@@ -411,6 +411,9 @@ def other_workloads(args, env):
                 "rays": det.get("rays"), "value_repeated_frame": det.get("value_repeated_frame"),
                 "foam_pack_ms": det.get("foam_pack_ms"), "foam_csr": det.get("foam_csr"),
                 "matches_gpu_bitwise": cb.get("matches_gpu_bitwise"),
+                "literal_reference_scan": ({k: (cb.get("literal_reference_scan") or {}).get(k) for k in
+                                            ("matches_gpu_bitwise", "rays", "share_of_the_step", "error")
+                                            if k in (cb.get("literal_reference_scan") or {})} or None),
                 "points_grad_rel_l2": cb.get("points_grad_rel_l2"), "attr_grad_rel_l2": cb.get("attr_grad_rel_l2"),
                 "grads_within_1e-3": (None if "points_grad_within_1e-3" not in cb else
                                       bool(cb["points_grad_within_1e-3"] and cb["attr_grad_within_1e-3"])),
@@ -550,7 +553,17 @@ def run_workload(args, W, env):
         for k in range(1, min(args.warmup + args.steps, 24) + 1):
             c, r_np, s_np = make_view(k)
             fresh.append(device_view(c, torch.from_numpy(r_np).to(dev), torch.from_numpy(s_np).to(dev)))
+    # (24 views at most are resident; a run with more steps cycles through them, and a view met again would find the ray
+    # order / tile order the pipeline keyed on its tensors: the per-ray caches are dropped at every wrap, so that a
+    # re-used view is traced like a new one -- ADVICE r5)
     view_of_step = (lambda i: fresh[i % len(fresh)]) if fresh else (lambda i: view0)
+
+    def forget_rays_at_wrap(i):
+        if fresh and i >= len(fresh) and i % len(fresh) == 0 and on_gpu:
+            pipe._order = None
+            pipe._trail = None
+            pipe._tile_sets.clear()
+            pipe._tiles = None
 
     def step(record, view):
         rays, start = view["rays"], view["start"]
@@ -625,6 +638,7 @@ def run_workload(args, W, env):
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        forget_rays_at_wrap(args.warmup + i)
         step(True, view_of_step(args.warmup + i))
     sync()
     if world > 1:
@@ -688,7 +702,9 @@ def run_workload(args, W, env):
         detail["tile_order"] = mode_name
     detail["rays"] = "one frame / batch traced over and over (--repeat-frame)" if not fresh else \
         f"new in every step ({len(fresh)} views resident: " + \
-        ("a shuffled batch per step" if W["kind"] == "batch" else f"a camera path, {VIEW_STEP_DEGREES} degrees per step") + ")"
+        ("a shuffled batch per step" if W["kind"] == "batch" else f"a camera path, {VIEW_STEP_DEGREES} degrees per step") + \
+        ("" if args.warmup + args.steps <= len(fresh) else
+         f"; {args.warmup + args.steps} steps cycle through them, the pipeline's per-ray caches dropped at every wrap") + ")"
     if repeated is not None:
         total = frame_rays if (strong or world == 1) else frame_rays * world
         repeated["value"] = round(total / (repeated["ms_per_step"] * 1e-3) / 1e6, 3)
@@ -1028,6 +1044,32 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
         same = same and bool(np.array_equal(f["depth"].view(np.uint32), last["out"]["depth"].cpu().numpy()[sl].view(np.uint32)))
         same = same and bool(np.array_equal(f["depth_indices"].view(np.uint32).reshape(-1),
                                             last["out"]["depth_indices"].cpu().numpy()[sl].view(np.uint32).reshape(-1)))
+    # The timed comparison above runs the oracle's "filtered" mode -- the CPU mirror of the kernels' own evaluation.  The
+    # link to the reference's LITERAL loop (every face divided, running minimum of the rounded quotients) is made here as
+    # well, untimed: a forward of at least every 3rd row and column (11 %) of the same frame / every 9th ray of the batch,
+    # more when the cores are fast enough, in the oracle's default mode against the same GPU output (VERDICT r5 weak #1b).
+    literal = None
+    try:
+        per_ray = tf / max(n, 1) * 2.0                    # the literal loop is about twice the filtered one on these cores
+        lit_stride = next((k for k in (1, 2, 3) if per_ray * total / (k * k) <= 8.0), 3)
+        r_l, s_l, _, sl_l, q_l, _ = sample(lit_stride)
+        t_l = time.perf_counter()
+        f_l = O.trace_forward(*foam_args, r_l, s_l, depth_quantiles=q_l, diff=diff, num_threads=cores)
+        t_l = time.perf_counter() - t_l
+        gpu_l = last["out"]["rgba"].cpu().numpy()[sl_l]
+        same_l = bool(np.array_equal(f_l["rgba"].view(np.uint32), gpu_l.view(np.uint32)))
+        if last["out"].get("num_intersections") is not None:
+            same_l = same_l and bool(np.array_equal(f_l["num_intersections"].reshape(-1),
+                                                    last["out"]["num_intersections"].cpu().numpy()[sl_l].view(np.uint32).reshape(-1)))
+        n_l = r_l.size // 6
+        literal = {"scan": "the reference's loop as written (tracing_utils.cuh:43-67): every face divided, strict '<' on the "
+                           "rounded quotients -- oracle scan_cell_reference, the oracle's default mode",
+                   "rays": int(n_l), "share_of_the_step": round(n_l / total, 4),
+                   "sample": "the whole frame / batch" if lit_stride == 1 else
+                             (f"every {lit_stride}th row and column" if image else f"every {lit_stride * lit_stride}th ray"),
+                   "matches_gpu_bitwise": same_l, "seconds": round(t_l, 2)}
+    except Exception as exc:  # noqa: BLE001
+        literal = {"error": repr(exc)}
     out = {
         "value": round(n / (tf + tb) / 1e6, 5),
         "unit": "Mrays/s",
@@ -1040,6 +1082,9 @@ def cpu_baseline(args, W, pipe, fm, rays_np, start_np, last, grad_rgba, foam_dev
                     f"in the walk, BASELINE.md section 3), the scan evaluated as the kernels evaluate it; forward {tf:.2f}s"
                   + ("" if b is None else f" + backward {tb:.2f}s") + "; fp16 face table prebuilt (excluded)",
         "matches_gpu_bitwise": same,
+        "matches_gpu_bitwise_scan_mode": "filtered: the oracle's mirror of the kernels' evaluation (tournament on products, "
+                                         "certificate, fail-safe, dividing fallback) -- the timed run",
+        "literal_reference_scan": literal,
         # how often the filtered scan's certificate fails on this workload (the same evaluation the kernels run)
         "scan_contested_cells": contested.get("cells"), "scan_cells": contested.get("scans"),
         "scan_contested_rate": (round(contested["cells"] / max(contested["scans"], 1), 7) if contested else None),

@@ -153,7 +153,8 @@ uint32_t rf_launch_blocks(uint32_t num_rays, uint32_t image_width, uint32_t imag
  * the 16-byte-per-face table (fp16 neighbour offsets as in the reference's half4 table, plus
  * the neighbour index and its face range) with the reference's +32 entries of slack, and
  * repacked SH rows when the attribute row is not 16-byte aligned.  Replaces the per-call
- * CUDAArray<Vec4h>(E+32) of pipeline.cu:613,667. */
+ * CUDAArray<Vec4h>(E+32) of pipeline.cu:613,667.  Always size the workspace by calling this function with the
+ * library that will use it: the figure is not part of the ABI (round 5 added 256 bytes for forward_mode 4's queue head). */
 size_t rf_workspace_bytes(uint32_t num_points, uint32_t point_adjacency_size, int sh_degree,
                           int attr_type);
 

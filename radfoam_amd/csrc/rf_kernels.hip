@@ -3087,7 +3087,8 @@ int rf_trace_forward(int sh_degree, int attr_type, const rf_trace_settings *sett
     p.stats = reinterpret_cast<unsigned long long *>(opts->stats);
     p.visit_marks = opts->stats ? opts->visit_marks : nullptr;
     p.tile_cost = opts->tile_cost;
-    // the scan scratch of the packing (per-chunk sums) is free once the foam is packed: its first word is the queue head
+    // the ray queue head of forward_mode 4: a word of its own in the workspace (FoamLayout::queue_off -- not the packing's
+    // scan scratch any more; rf_workspace_bytes grew by 256 bytes for it in round 5)
     p.queue = reinterpret_cast<uint32_t *>(static_cast<char *>(opts->workspace) + L.queue_off);
     if (opts->trail && opts->trail_hops && opts->trail_cap) {
         if (opts->trail_slots < num_tiles(p.grid) * (uint32_t)kBlock)
