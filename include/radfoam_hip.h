@@ -227,6 +227,25 @@ int rf_trace_benchmark(int sh_degree, int attr_type, const rf_trace_settings *se
                        const rf_camera *camera, const uint32_t *start_point_index,
                        uint32_t *ray_rgba, const rf_launch_opts *opts, void *stream);
 
+/* A cost prior for the 16x16-pixel tiles of a frame that has never been traced (no counterpart in the reference, whose
+ * launches take pixels in index order; benchmark.py:95-139 renders another camera every frame, so the step counts a
+ * previous trace measured -- rf_launch_opts.tile_cost -- do not exist for it).  rf_build_cost_grid fills `grid`
+ * (rf_cost_grid_bytes(res) bytes of device memory) with a res^3 voxel grid over the points' bounding box: per voxel the
+ * cells a line crosses per unit length (1.455 n^(1/3), n = points per unit volume) and the mean density (last attribute).
+ * rf_estimate_tile_cost marches five rays of every tile through it -- rays: float[height][width][6] on the device, or
+ * rays == NULL and `camera` (host struct, as for rf_trace_benchmark) -- until the transmittance exp(-optical depth) falls
+ * below weight_threshold, the ray leaves the box or max_intersections steps are estimated, and writes the estimated
+ * steps of each tile's longest ray to tile_cost[number of tiles] (row-major tiles, the layout of rf_launch_opts.tile_cost).
+ * The host turns that into a rf_launch_opts.tile_order; any order gives the same results. */
+size_t rf_cost_grid_bytes(uint32_t res);
+
+int rf_build_cost_grid(const float *points, const void *attributes, int attr_type, uint32_t attr_dim, uint32_t num_points,
+                       uint32_t res, void *grid, size_t grid_bytes, void *stream);
+
+int rf_estimate_tile_cost(const void *grid, uint32_t res, const float *rays, const rf_camera *camera, uint32_t width,
+                          uint32_t height, float weight_threshold, uint32_t max_intersections, uint32_t *tile_cost,
+                          void *stream);
+
 /* Number of adjacency entries of a foam = point_adjacency_offsets[num_points], read back from the device (one
  * 4-byte copy on `stream`, which is synchronised).  Pipeline::trace_benchmark (src/tracing/pipeline.h:117-126)
  * receives no adjacency size, while rf_workspace_bytes() / rf_trace_benchmark() need it on the host: a

@@ -106,6 +106,9 @@ SYMBOLS = {
     "rf_scatter_grad_rows": (_INT, [_P, _U32, _U32, _U32, _INT, _P, _P, _P]),
     "rf_compact_grad_rows_pitched": (_INT, [_P, _P, _U32, _U32, _U32, _U32, _P, _P, _P]),
     "rf_scatter_grad_rows_pitched": (_INT, [_P, _U32, _U32, _U32, _U32, _INT, _P, _P, _P]),
+    "rf_cost_grid_bytes": (C.c_size_t, [_U32]),
+    "rf_build_cost_grid": (_INT, [_P, _P, _INT, _U32, _U32, _U32, _P, C.c_size_t, _P]),
+    "rf_estimate_tile_cost": (_INT, [_P, _U32, _P, C.POINTER(Camera), _U32, _U32, C.c_float, _U32, _P, _P]),
     "rf_trace_benchmark": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _P,
                                   C.POINTER(Camera), _P, _P, C.POINTER(LaunchOpts), _P]),
 }

@@ -574,20 +574,17 @@ class DataParallelPipeline:
             rgb_out, grad_in = cut(rgb_out), cut(grad_in)
             depth_quantiles, depth_indices, depth_grad_in = cut(depth_quantiles), cut(depth_indices), cut(depth_grad_in)
             ray_error = None if ray_error is None else cut(torch.broadcast_to(ray_error, lead))
+        if self.reduce == "mean" and self.shard == "caller":
+            # the mean over ranks = the sum of the ranks' gradients of loss / W: the backward is linear in the upstream
+            # gradients, so the 1 / W goes onto them (a few MB) instead of onto the summed flat buffer (half a GB at 2 M
+            # points and SH 3: a pass of its own); exact for power-of-two worlds.  point_error does not depend on them.
+            scale = 1.0 / world
+            grad_in = grad_in * scale
+            depth_grad_in = None if depth_grad_in is None else depth_grad_in * scale
         res = self.inner.trace_backward(points, attributes, point_adjacency, point_adjacency_offsets, rays, start_point,
                                         rgb_out, grad_in, depth_quantiles, depth_indices, depth_grad_in, ray_error,
                                         weight_threshold, max_intersections)
         self._exchange(res, image_shaped=full_rays.dim() == 3)
-        if self.reduce == "mean" and self.shard == "caller":
-            scale = 1.0 / world
-            flat = res.get("flat_grad")
-            ag = res["attr_grad"]
-            if flat is not None and ag.dtype == flat.dtype and \
-                    ag.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr():
-                flat.mul_(scale)
-            else:
-                res["points_grad"].mul_(scale)
-                ag.mul_(scale)
         if self.shard == "rows":
             res["ray_grad"] = torch.zeros_like(full_rays)      # the reference never writes it (pipeline_bindings.cpp:455)
         return res

@@ -268,6 +268,21 @@ class Pipeline:
         #: launches over a frame shape between two learnings of its tile orders when the rays keep changing (an order
         #: learnt on another camera of the same scene is worth as much as the frame's own: scripts/gpu_tile_order_stale.py)
         self.tile_order_refresh = 16
+        #: image-shaped launches over rays the pipeline has NOT traced before (another camera: benchmark.py:95-139, a new
+        #: training view): under "auto" the forward / render takes its block order from a cost PRIOR instead of the static
+        #: dealing -- a coarse grid of the foam (cells per unit length, mean density per voxel: rf_build_cost_grid, rebuilt
+        #: with the triangulation and every tile_prior_refresh geometry changes) marched by five rays per tile
+        #: (rf_estimate_tile_cost), longest estimate first per XCD.  Needs no previous trace of these rays; results do
+        #: not depend on it.  False: the static dealing for new rays (rounds 4-5).
+        self.tile_prior = True
+        self.tile_prior_resolution = 32
+        self.tile_prior_refresh = 64
+        #: the rule applied to the estimated costs (see tile_order()); None = "xcd:8" for launches of at most 16384
+        #: blocks (classes of 8 estimated steps, static order within a class), "tail" above
+        self.tile_prior_rule = None
+        self._prior = None          # {"topo": key, "points": key, "grid": tensor, "age": geometry changes since it was built}
+        self._prior_keep = None     # the order handed to the launch in flight
+        self._defaults = {}         # (height, width, device) -> the static block -> tile table
         self._tiles = None          # the tile orders used last (one entry of _tile_sets)
         self._tile_sets = {}        # frame shape -> its tile orders (a few shapes: training batches, evaluation frames)
         #: trace_forward records the cell every hop enters so that a trace_backward call on the same
@@ -343,6 +358,7 @@ class Pipeline:
         self._cache.clear()
         self._trail = None
         self._order = None
+        self._prior = None
 
     #: trace_forward takes the keyword-only ``record_trail`` (radfoam_amd.render.TraceRays passes it)
     accepts_record_trail = True
@@ -671,8 +687,10 @@ class Pipeline:
             trail = self._new_trail(opts, num_rays, dev)
         tiles_pending = None
         if opts.image_width:
-            tiles_pending = self._tile_cost_begin(opts, opts.image_height, opts.image_width, ray_keys[:2], dev,
-                                                  backward_follows=trail is not None)
+            tiles_pending = self._tile_cost_begin(
+                opts, opts.image_height, opts.image_width, ray_keys[:2], dev, backward_follows=trail is not None,
+                prior={"rays": rays_c, "camera": None, "foam": (points_c, attributes_c, adjacency_c, offsets_c),
+                       "settings": settings})
         elif opts.ray_order:
             tiles_pending = self._tile_cost_begin(opts, "flat", num_rays, ray_keys[:2], dev)
         with torch.cuda.device(dev):
@@ -708,7 +726,71 @@ class Pipeline:
         out["num_intersections"] = num_intersections
         return out
 
-    def _tile_cost_begin(self, opts, height, width, key, dev, backward_follows=False):
+    def _default_tiles(self, height, width, dev):
+        """The static block -> tile table of a launch shape (rf_launch_blocks), as an int64 device tensor."""
+        k = (height, width, dev)
+        d = self._defaults.get(k)
+        if d is None:
+            dims = (width, 0, 0) if height == "flat" else (height * width, width, height)
+            nb = int(self._lib.rf_launch_blocks(*dims, None))
+            host = (C.c_uint32 * nb)()
+            self._lib.rf_launch_blocks(*dims, host)
+            d = torch.tensor(list(host), dtype=torch.int64, device=dev)
+            while len(self._defaults) >= 16:
+                self._defaults.pop(next(iter(self._defaults)))
+            self._defaults[k] = d
+        return d
+
+    def _prior_grid(self, foam):
+        """The coarse cost grid of this foam (rf_build_cost_grid), rebuilt when the adjacency changes (a triangulation
+        rebuild: points were added, pruned or reordered) or after tile_prior_refresh changes of the geometry."""
+        points_c, attributes_c, adjacency_c, offsets_c = foam
+        topo = (_tensor_key(adjacency_c), _tensor_key(offsets_c), tuple(points_c.shape), points_c.device,
+                int(self.tile_prior_resolution))
+        pkey = (_tensor_key(points_c), _tensor_key(attributes_c))
+        pr = self._prior
+        if pr is not None and pr["topo"] == topo:
+            if pr["points"] == pkey:
+                return pr["grid"]
+            pr["age"] += 1
+            pr["points"] = pkey
+            if pr["age"] < int(self.tile_prior_refresh):
+                return pr["grid"]
+        res = int(self.tile_prior_resolution)
+        nbytes = int(self._lib.rf_cost_grid_bytes(res))
+        grid = pr["grid"] if (pr is not None and pr["grid"].numel() == nbytes and pr["grid"].device == points_c.device) \
+            else torch.empty(nbytes, dtype=torch.uint8, device=points_c.device)
+        with torch.cuda.device(points_c.device):
+            rc = self._lib.rf_build_cost_grid(_ptr(points_c), _ptr(attributes_c), self._attr_type, self._attr_dim,
+                                              points_c.size(0), res, _ptr(grid), nbytes, _stream_ptr(points_c.device))
+        _lib.check(rc)
+        self._prior = {"topo": topo, "points": pkey, "grid": grid, "age": 0, "refs": (adjacency_c, offsets_c)}
+        return grid
+
+    def estimate_tile_cost(self, foam, height, width, rays=None, camera=None, settings=None):
+        """int32 [tiles]: estimated steps of every 16x16 tile's longest ray (rf_estimate_tile_cost) -- what a forward
+        over these rays would report as rf_launch_opts.tile_cost, without tracing anything."""
+        dev = foam[0].device
+        grid = self._prior_grid(foam)
+        settings = settings or self._settings(None, None)
+        tiles = ((height + 15) // 16) * ((width + 15) // 16)
+        cost = torch.empty(tiles, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = self._lib.rf_estimate_tile_cost(_ptr(grid), int(self.tile_prior_resolution), _ptr(rays),
+                                                 C.byref(camera) if camera is not None else None, int(width), int(height),
+                                                 float(settings.weight_threshold), int(settings.max_intersections),
+                                                 _ptr(cost), _stream_ptr(dev))
+        _lib.check(rc)
+        return cost
+
+    def _prior_tile_order(self, height, width, dev, prior):
+        cost = self.estimate_tile_cost(prior["foam"], height, width, rays=prior["rays"], camera=prior["camera"],
+                                       settings=prior["settings"])
+        default = self._default_tiles(height, width, dev)
+        rule = self.tile_prior_rule or ("xcd:8" if default.numel() <= 16384 else "tail")
+        return tile_order(cost, default, rule).to(torch.int32).contiguous()
+
+    def _tile_cost_begin(self, opts, height, width, key, dev, backward_follows=False, prior=None):
         """Decide what this launch does about tile orders.  Returns what _tile_cost_end needs when the launch is to report
         the cost of its tiles (rf_launch_opts.tile_cost), else None.
 
@@ -723,14 +805,22 @@ class Pipeline:
         if mode in (None, "static") or (height != "flat" and (height < 16 or width < 16)):
             return None
         t = self._tile_sets.get((height, width))
-        if t is not None and t["mode"] == mode and t["default"].device == dev:
+        known = t is not None and t["mode"] == mode and t["default"].device == dev
+        same = known and t["key"] == key
+        if known:
             t["age"] += 1
-            same = t["key"] == key
-            if mode == "auto" and not same and height != "flat":
-                opts.tile_order = None              # another camera's order: the static dealing is better for this launch
-            if same or (t["age"] < int(self.tile_order_refresh) and not (mode == "auto" and backward_follows and
-                                                                          height != "flat")):
-                return None
+        if mode == "auto" and not same and height != "flat":
+            # rays this pipeline has not traced: another camera's measured order does not transfer (the static dealing is
+            # better than it); the order a cost prior of THESE rays gives does (tile_prior)
+            opts.tile_order = None
+            self._prior_keep = None
+            if self.tile_prior and prior is not None:
+                order = self._prior_tile_order(height, width, dev, prior)
+                opts.tile_order = order.data_ptr()
+                self._prior_keep = order
+        if known and (same or (t["age"] < int(self.tile_order_refresh) and not (mode == "auto" and backward_follows and
+                                                                                  height != "flat"))):
+            return None
         tiles = (width + 255) // 256 if height == "flat" else ((height + 15) // 16) * ((width + 15) // 16)
         cost = torch.zeros(tiles, dtype=torch.int32, device=dev)
         opts.tile_cost = cost.data_ptr()
@@ -747,11 +837,7 @@ class Pipeline:
         dev = cost.device
         t = self._tile_sets.get((height, width))
         if t is None or t["default"].device != dev:
-            dims = (width, 0, 0) if height == "flat" else (height * width, width, height)
-            nb = int(self._lib.rf_launch_blocks(*dims, None))
-            host = (C.c_uint32 * nb)()
-            self._lib.rf_launch_blocks(*dims, host)
-            t = {"shape": (height, width), "default": torch.tensor(list(host), dtype=torch.int64, device=dev)}
+            t = {"shape": (height, width), "default": self._default_tiles(height, width, dev)}
         default = t["default"]
         if mode != "auto":
             rules = (mode, mode)
@@ -964,7 +1050,9 @@ class Pipeline:
                                  image=(cam.height, cam.width))
         dev = points_c.device
         cam_key = ("camera", bytes(cam), self._tkey(start_point))
-        tiles_pending = self._tile_cost_begin(opts, cam.height, cam.width, cam_key, dev)
+        tiles_pending = self._tile_cost_begin(
+            opts, cam.height, cam.width, cam_key, dev,
+            prior={"rays": None, "camera": cam, "foam": (points_c, attributes_c, adjacency_c, offsets_c), "settings": settings})
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_benchmark(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),

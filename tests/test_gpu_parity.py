@@ -1163,3 +1163,57 @@ def test_subnormal_exit_distances_and_underflowing_foams(forward_mode):
         got, _ = _run_forward(pipe, fs, r, st)
         np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), want["rgba"].view(np.uint32), err_msg=str(e))
         np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), want["num_intersections"], err_msg=str(e))
+
+
+def test_tile_prior_ranks_tiles_and_does_not_change_results(foam_factory):
+    """rays the pipeline has not traced before take their block order from a cost prior (a coarse grid of
+    the foam marched by five rays per tile: rf_build_cost_grid / rf_estimate_tile_cost) instead of the static dealing.  The
+    prior only orders blocks: forward outputs with and without it are the same bits (and the oracle's), gradients within the
+    usual bars; its estimate ranks the tiles as a trace of the same rays does (Spearman > 0.6 on this frame) -- through
+    trace_forward's ray tensor and through trace_benchmark's camera alike."""
+    import radfoam
+
+    d = 2
+    fm = foam_factory(20000, d, 17)
+    cam, rays, start = H.camera_setup(fm, 320, 208, position=(0.4, 0.3, -2.6))
+    ref = O.trace_forward(d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"], rays, start)
+    outs = {}
+    for prior in (True, False):
+        pipe = _pipeline(d)
+        pipe.tile_prior = prior
+        got, (p, a, adj, off, r, s) = _run_forward(pipe, fm, rays, start)
+        assert (pipe._prior_keep is not None) == prior          # new rays: the launch did / did not get a prior order
+        g = torch.randn(r.shape[:-1] + (4,), generator=torch.Generator().manual_seed(2)).to(DEV)
+        bwd = pipe.trace_backward(p, a, adj, off, r, s, got["rgba"].to(DEV), g)
+        outs[prior] = (got, {k: bwd[k].cpu() for k in ("points_grad", "attr_grad")})
+        np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+        np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
+        if prior:
+            order = pipe._prior_keep.cpu().numpy()
+            tiles = ((208 + 15) // 16) * ((320 + 15) // 16)
+            assert sorted(order[order < tiles].tolist()) == list(range(tiles))      # every tile exactly once
+            est = pipe.estimate_tile_cost((p, a, adj, off), 208, 320, rays=r).float().cpu()
+            ni = got["num_intersections"].reshape(208, 320).float()
+            measured = ni.view(13, 16, 20, 16).amax(dim=(1, 3)).reshape(-1)
+            rank = lambda x: torch.argsort(torch.argsort(x)).double()
+            rx, ry = rank(est) - rank(est).mean(), rank(measured) - rank(measured).mean()
+            assert float((rx * ry).sum() / (rx.norm() * ry.norm())) > 0.6
+    for k in ("points_grad", "attr_grad"):
+        ok, rel, worst = H.grad_close(outs[True][1][k].numpy(), outs[False][1][k].numpy())
+        assert ok and rel < 1e-5, (k, rel, worst)
+    # the render path: the camera instead of a ray tensor
+    a16 = torch.from_numpy(fm["attributes"].astype(np.float16)).to(DEV)
+    words = {}
+    for prior in (True, False):
+        rend = radfoam.create_pipeline(d, torch.float16)
+        rend.tile_prior = prior
+        p, _, adj, off = H.to_torch_foam(fm, DEV)
+        diff = rend.build_adjacent_diff(p, adj, off)
+        out8 = torch.zeros((208, 320), dtype=torch.uint32, device=DEV)
+        camt = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in cam.items()}
+        rend.trace_benchmark(p, a16, adj, off, diff, camt, torch.tensor([int(start)], dtype=torch.int64).to(torch.uint32).to(DEV),
+                             out8, weight_threshold=0.05)
+        words[prior] = out8.cpu().numpy().view(np.uint32).copy()
+        assert (rend._prior_keep is not None) == prior
+    np.testing.assert_array_equal(words[True], words[False])
+    assert words[True].any()
