@@ -246,6 +246,29 @@ int rf_estimate_tile_cost(const void *grid, uint32_t res, const float *rays, con
                           uint32_t height, float weight_threshold, uint32_t max_intersections, uint32_t *tile_cost,
                           void *stream);
 
+/* Block -> tile tables (rf_launch_opts.tile_order) from a cost map (rf_launch_opts.tile_cost of a forward, or
+ * rf_estimate_tile_cost), built on the device in one launch; no counterpart in the reference.  Up to two tables per call
+ * (order_b may be NULL), each uint32[rf_launch_blocks(num_rays, image_width, image_height)]; image_width = 0: a flat batch
+ * of num_rays rays (its 256-slot groups).  rule 1, param q: every XCD keeps the tiles the static dealing gives it and takes
+ * them longest first in classes of q steps (static order within a class); rule 2, param n: the static order, except that
+ * the n cheapest tiles of the frame come last, the longest of them first.  At most 65536 blocks. */
+int rf_build_tile_orders(const uint32_t *tile_cost, uint32_t num_rays, uint32_t image_width, uint32_t image_height,
+                         uint32_t rule_a, uint32_t param_a, uint32_t *order_a, uint32_t rule_b, uint32_t param_b,
+                         uint32_t *order_b, void *stream);
+
+/* A frame may take the order ANOTHER frame's trace measured only when it shows nearly the same picture (a camera path).
+ * rf_tile_order_reference records five rays of the frame an order was learnt on into reference[40] (device floats; the
+ * frame is given as for rf_estimate_tile_cost -- a ray tensor with one start_point_index per ray, or `camera` with ONE);
+ * rf_gate_tile_order compares the same five rays of a new frame with it -- angle between the directions plus the shift of
+ * the origin relative to its distance from the entry cell's point, at most max_angle_radians for every sample -- and
+ * writes `order` = learnt_order if so, the static dealing if not, plus (optional) *verdict = 1 / 0; all on the device. */
+int rf_tile_order_reference(const float *rays, const rf_camera *camera, const uint32_t *start_point_index, const float *points,
+                            uint32_t image_width, uint32_t image_height, float *reference, void *stream);
+
+int rf_gate_tile_order(const float *rays, const rf_camera *camera, const float *reference, uint32_t image_width,
+                       uint32_t image_height, float max_angle_radians, const uint32_t *learnt_order, uint32_t *order,
+                       uint32_t *verdict, void *stream);
+
 /* Number of adjacency entries of a foam = point_adjacency_offsets[num_points], read back from the device (one
  * 4-byte copy on `stream`, which is synchronised).  Pipeline::trace_benchmark (src/tracing/pipeline.h:117-126)
  * receives no adjacency size, while rf_workspace_bytes() / rf_trace_benchmark() need it on the host: a

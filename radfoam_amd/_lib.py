@@ -109,6 +109,9 @@ SYMBOLS = {
     "rf_cost_grid_bytes": (C.c_size_t, [_U32]),
     "rf_build_cost_grid": (_INT, [_P, _P, _INT, _U32, _U32, _U32, _P, C.c_size_t, _P]),
     "rf_estimate_tile_cost": (_INT, [_P, _U32, _P, C.POINTER(Camera), _U32, _U32, C.c_float, _U32, _P, _P]),
+    "rf_build_tile_orders": (_INT, [_P, _U32, _U32, _U32, _U32, _U32, _P, _U32, _U32, _P, _P]),
+    "rf_tile_order_reference": (_INT, [_P, C.POINTER(Camera), _P, _P, _U32, _U32, _P, _P]),
+    "rf_gate_tile_order": (_INT, [_P, C.POINTER(Camera), _P, _U32, _U32, C.c_float, _P, _P, _P, _P]),
     "rf_trace_benchmark": (_INT, [_INT, _INT, C.POINTER(TraceSettings), _U32, _P, _P, _U32, _P, _P, _P,
                                   C.POINTER(Camera), _P, _P, C.POINTER(LaunchOpts), _P]),
 }

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SOURCES = [os.path.join(_CSRC, n) for n in ("rf_kernels.hip", "rf_scene_ops.hip", "rf_adjacency.hip", "rf_grad_exchange.hip", "rf_delaunay.hip", "rf_tile_prior.hip")]
-HEADERS = [os.path.join(_CSRC, n) for n in ("rf_math.hpp", "rf_foam.hpp", "rf_wave.hpp", "rf_host.hpp", "rf_star.hpp")] + [
+HEADERS = [os.path.join(_CSRC, n) for n in ("rf_math.hpp", "rf_foam.hpp", "rf_wave.hpp", "rf_host.hpp", "rf_star.hpp", "rf_tiles.hpp")] + [
     os.path.join(os.path.dirname(_HERE), "include", "radfoam_hip.h")]
 OBJ_DIR = os.path.join(_CSRC, "_obj")
 OUTPUT = os.path.join(_HERE, "libradfoam_hip.so")

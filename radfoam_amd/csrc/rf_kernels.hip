@@ -42,6 +42,7 @@
 #include "rf_foam.hpp"
 #include "rf_host.hpp"
 #include "rf_math.hpp"
+#include "rf_tiles.hpp"
 #include "rf_wave.hpp"
 
 namespace rf {
@@ -138,43 +139,16 @@ constexpr int kBlock = 256;
 // (rf_launch_opts.tile_order; radfoam_amd/pipeline.py: tile_order) -- every XCD keeps the tiles dealt to it here but takes
 // them longest first, or keeps this order and moves the cheapest tiles to the end (1080p frame: forward 4.70 -> 4.42 ms,
 // backward 3.88 -> 3.73; the render path 2.51 -> 2.26 ms).
-inline __host__ __device__ uint32_t dealt_tile(uint32_t b, uint32_t chunk, uint32_t rounds) {
-    const uint32_t x = b & 7u, i = b >> 3;
-    uint32_t j = i / chunk;
-    const uint32_t o = i - j * chunk;
-    // rounds are visited from both ends of the image towards its middle (0, last, 1, last-1, ...):
-    // the blocks still running when the launch drains are then neighbours in the image, of
-    // similar length, instead of the longest walks of the frame
-#ifdef RF_DEAL_MIDDLE_FIRST
-    j = rounds - 1u - j;       // experiment: the same sequence backwards -- the middle of the image first, its ends last
-#endif
-    j = (j & 1u) ? rounds - 1u - (j >> 1) : (j >> 1);
-    return (j * 8u + ((x + 3u * j) & 7u)) * chunk + o;
-}
+// (dealt_tile / tile counts: rf_tiles.hpp, shared with the device-side builder of tile orders in rf_tile_prior.hip)
+inline __host__ __device__ uint32_t num_tiles(const RayGrid &g) { return tile_count(g.num_rays, g.img_w, g.img_h); }
 
-inline __host__ __device__ uint32_t num_tiles(const RayGrid &g) {
-    if (g.img_w) return ((g.img_w + 15u) >> 4) * ((g.img_h + 15u) >> 4);
-    return (g.num_rays + (uint32_t)kBlock - 1u) / (uint32_t)kBlock;
-}
-
-inline __host__ __device__ uint32_t tile_chunk(const RayGrid &g) {
-    if (g.img_w) {
-        const uint32_t tiles_x = (g.img_w + 15u) >> 4;
-        return tiles_x > 3u ? (tiles_x + 3u) >> 2 : 1u;
-    }
-    return 16u;
-}
+inline __host__ __device__ uint32_t tile_chunk(const RayGrid &g) { return tile_chunk_of(g.img_w); }
 
 constexpr uint32_t kResidentBlocks = 1024;   // 256 CUs x 4 blocks: a launch of the eager forward (4 waves per SIMD) that is resident at once
 constexpr int kEagerBlocks = 6;
 
 // blocks to launch: whole rounds of 8 chunks
-inline uint32_t launch_blocks(const RayGrid &g) {
-    const uint32_t nt = num_tiles(g);
-    if (nt == 0) return 0;
-    const uint32_t round = 8u * tile_chunk(g);
-    return (nt + round - 1u) / round * round;
-}
+inline uint32_t launch_blocks(const RayGrid &g) { return launch_block_count(g.num_rays, g.img_w, g.img_h); }
 
 // ray and trail slot of thread `tid` of block `block` of a launch of `nblocks` blocks; false when it owns no ray (slot ==
 // kNone: not even a slot)

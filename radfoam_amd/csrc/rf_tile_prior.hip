@@ -24,6 +24,7 @@
 
 #include "../../include/radfoam_hip.h"
 #include "rf_host.hpp"
+#include "rf_tiles.hpp"
 
 namespace rf {
 
@@ -238,6 +239,163 @@ __global__ __launch_bounds__(256) void tile_cost_estimate_kernel(PriorView p, co
     tile_cost[tile] = (uint32_t)(longest + 0.5f);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile orders from a cost map, on the device.  Rounds 4-5 turned a forward's tile_cost into the block -> tile tables of the
+// next launches with two dozen small torch operations (sort, gather, kthvalue, ...): 0.2-0.25 ms on the launch stream
+// between the forward and whatever follows it -- as much as the backward's order then gained (profiles/r06/c_*).  One
+// launch of 8 blocks does the same: block x owns XCD x's column of the static dealing (positions i = 0 .. rows-1, block
+// b = 8 i + x), gives every position a 64-bit key {rule-dependent rank, position}, sorts the column (bitonic, in LDS) and
+// writes the tiles in that order.
+//   rule 1 "xcd:q"   longest first in classes of q steps, the static order within a class (forward / render of a frame
+//                    whose own costs are known);
+//   rule 2 "tail:n"  the static order, except that the n cheapest tiles of the frame come last, the longest of them first
+//                    (backward; flat batches).  The threshold is the n-th smallest cost of the whole frame: every block
+//                    histograms the frame for itself (costs clamp at 4095 for the histogram only).
+// Tiles past the end of the frame (padding blocks of the last round) go last under both rules.
+constexpr uint32_t kOrderRuleClasses = 1, kOrderRuleTail = 2;
+constexpr uint32_t kHistBins = 4096;
+
+struct OrderJob {
+    uint32_t rule, param;
+    uint32_t *out;
+};
+
+__global__ __launch_bounds__(256) void tile_orders_kernel(const uint32_t *__restrict__ cost, uint32_t num_rays, uint32_t width,
+                                                          uint32_t height, uint32_t rows_pow2, OrderJob job0, OrderJob job1) {
+    extern __shared__ unsigned long long s_keys[];                 // rows_pow2 entries
+    __shared__ uint32_t s_hist[kHistBins];
+    __shared__ uint32_t s_limit;
+    const OrderJob job = blockIdx.y == 0 ? job0 : job1;
+    const uint32_t x = blockIdx.x;
+    const uint32_t nt = tile_count(num_rays, width, height);
+    const uint32_t chunk = tile_chunk_of(width);
+    const uint32_t nblocks = launch_block_count(num_rays, width, height);
+    const uint32_t rows = nblocks >> 3, rounds = nblocks / (8u * chunk);
+    uint32_t limit = 0;
+    if (job.rule == kOrderRuleTail) {
+        for (uint32_t i = threadIdx.x; i < kHistBins; i += 256u) s_hist[i] = 0u;
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < nt; t += 256u) {
+            const uint32_t c = cost[t];
+            atomicAdd(&s_hist[c < kHistBins ? c : kHistBins - 1u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t count = job.param < 1u ? 1u : (job.param > nt ? nt : job.param), acc = 0, l = 0;
+            for (l = 0; l < kHistBins; ++l) {
+                acc += s_hist[l];
+                if (acc >= count) break;
+            }
+            s_limit = l < kHistBins - 1u ? l : 0xFFFFFFFFu;          // the last bin holds everything above it too
+        }
+        __syncthreads();
+        limit = s_limit;
+    }
+    const uint32_t q = job.param ? job.param : 1u;
+    for (uint32_t i = threadIdx.x; i < rows_pow2; i += 256u) {
+        unsigned long long key = ~0ull;                             // padding of the sort
+        if (i < rows) {
+            const uint32_t tile = dealt_tile(i * 8u + x, chunk, rounds);
+            const bool valid = tile < nt;
+            const uint32_t c = valid ? cost[tile] : 0u;
+            uint32_t rank;
+            if (job.rule == kOrderRuleTail) {
+                const uint32_t big = rows + 1u;
+                const uint32_t cc = c < (1u << 24) ? c : (1u << 24);
+                rank = !valid ? big + (1u << 25) : (c <= limit ? big + ((1u << 24) - cc) : i);
+            } else {
+                rank = !valid ? 0xFFFFFFFEu : 0x7FFFFFFFu - (c / q < 0x7FFFFFFFu ? c / q : 0x7FFFFFFFu);
+            }
+            key = ((unsigned long long)rank << 32) | (unsigned long long)i;
+        }
+        s_keys[i] = key;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= rows_pow2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < rows_pow2; i += 256u) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = s_keys[i], b = s_keys[l];
+                    const bool up = (i & k) == 0u;
+                    if ((a > b) == up) {
+                        s_keys[i] = b;
+                        s_keys[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < rows; i += 256u) {
+        const uint32_t pos = (uint32_t)(s_keys[i] & 0xFFFFFFFFull);
+        job.out[i * 8u + x] = dealt_tile(pos * 8u + x, chunk, rounds);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// May a frame take the block order that ANOTHER frame's trace measured?  Only when it shows nearly the same picture: a
+// camera path (a viewer, a fly-through) moves a pixel or two per frame, and the cost map with it; another camera of a
+// data set does not, and its order is worse than the static dealing (profiles/r04/d_tile_order_*).  A reference record of
+// the learnt frame -- five of its rays (the centre of the frame and of its quadrants) and, per ray, the distance from the
+// origin to the point of its entry cell (the nearest thing the camera can see move) -- is compared with the same five rays
+// of the new frame: the frames are coherent when, for every sample, the angle between the directions plus the shift of
+// the origin relative to that distance stays below max_angle (radians).  Decided on the device: no synchronisation.
+constexpr uint32_t kRefSamples = 5, kRefFloats = 8;
+
+__device__ __forceinline__ void ref_sample_pixel(uint32_t s, uint32_t width, uint32_t height, uint32_t &x, uint32_t &y) {
+    const uint32_t fx[5] = {2u, 1u, 3u, 1u, 3u}, fy[5] = {2u, 1u, 1u, 3u, 3u};
+    x = (width * fx[s]) >> 2;
+    y = (height * fy[s]) >> 2;
+    x = x < width ? x : width - 1u;
+    y = y < height ? y : height - 1u;
+}
+
+__global__ void tile_reference_kernel(PriorView v, const uint32_t *__restrict__ start, const float *__restrict__ points,
+                                      float *__restrict__ ref) {
+    const uint32_t s = threadIdx.x;
+    if (s >= kRefSamples) return;
+    uint32_t x, y;
+    ref_sample_pixel(s, v.width, v.height, x, y);
+    float o[3], d[3] = {0.0f, 0.0f, 0.0f};
+    if (!prior_ray(v, x, y, o, d)) d[0] = d[1] = d[2] = 0.0f;
+    // (a camera has ONE entry cell; a ray tensor one per ray)
+    const float *pp = points + 3 * (size_t)start[v.rays ? (size_t)y * v.width + x : 0];
+    const float dx = pp[0] - o[0], dy = pp[1] - o[1], dz = pp[2] - o[2];
+    float *r = ref + s * kRefFloats;
+    r[0] = o[0]; r[1] = o[1]; r[2] = o[2];
+    r[3] = d[0]; r[4] = d[1]; r[5] = d[2];
+    r[6] = sqrtf(dx * dx + dy * dy + dz * dz);
+    r[7] = 0.0f;
+}
+
+__global__ __launch_bounds__(256) void tile_order_gate_kernel(PriorView v, const float *__restrict__ ref, float max_angle,
+                                                              const uint32_t *__restrict__ learnt, uint32_t *__restrict__ out,
+                                                              uint32_t *__restrict__ verdict) {
+    const uint32_t nblocks = launch_block_count(v.width * v.height, v.width, v.height);
+    const uint32_t chunk = tile_chunk_of(v.width);
+    bool coherent = true;
+#pragma unroll
+    for (uint32_t s = 0; s < kRefSamples; ++s) {
+        uint32_t x, y;
+        ref_sample_pixel(s, v.width, v.height, x, y);
+        float o[3], d[3];
+        const float *r = ref + s * kRefFloats;
+        if (!prior_ray(v, x, y, o, d)) {
+            coherent = false;
+            continue;
+        }
+        const float cx = d[1] * r[5] - d[2] * r[4], cy = d[2] * r[3] - d[0] * r[5], cz = d[0] * r[4] - d[1] * r[3];
+        const float angle = atan2f(sqrtf(cx * cx + cy * cy + cz * cz), d[0] * r[3] + d[1] * r[4] + d[2] * r[5]);
+        const float sx = o[0] - r[0], sy = o[1] - r[1], sz = o[2] - r[2];
+        const float rel = sqrtf(sx * sx + sy * sy + sz * sz) / fmaxf(r[6], 1e-30f);
+        if (!(angle + rel <= max_angle)) coherent = false;      // NaN anywhere: not coherent
+    }
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b == 0 && verdict) *verdict = coherent ? 1u : 0u;
+    if (b < nblocks) out[b] = coherent ? learnt[b] : dealt_tile(b, chunk, nblocks / (8u * chunk));
+}
+
 }  // namespace rf
 
 using namespace rf;
@@ -312,6 +470,76 @@ int rf_estimate_tile_cost(const void *grid, uint32_t res, const float *rays, con
     hipLaunchKernelGGL(tile_cost_estimate_kernel, dim3((tiles + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), p,
                        header, voxels, res, tiles_x, tiles, tile_cost);
     return check_launch("rf_estimate_tile_cost");
+}
+
+static uint32_t order_rule_id(const char *who, uint32_t rule) {
+    (void)who;
+    return rule == kOrderRuleClasses || rule == kOrderRuleTail ? rule : 0u;
+}
+
+int rf_build_tile_orders(const uint32_t *tile_cost, uint32_t num_rays, uint32_t image_width, uint32_t image_height,
+                         uint32_t rule_a, uint32_t param_a, uint32_t *order_a, uint32_t rule_b, uint32_t param_b,
+                         uint32_t *order_b, void *stream) {
+    g_err[0] = 0;
+    if (!tile_cost || !order_a) return fail(RF_ERR_INVALID_ARGUMENT, "rf_build_tile_orders: null pointer");
+    if (!order_rule_id("a", rule_a) || (order_b && !order_rule_id("b", rule_b)))
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_build_tile_orders: rule must be 1 (classes) or 2 (tail)");
+    if (image_width && (uint64_t)image_width * image_height != num_rays)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_build_tile_orders: image_width * image_height must equal num_rays");
+    const uint32_t nblocks = launch_block_count(num_rays, image_width, image_height);
+    if (nblocks == 0) return RF_OK;
+    const uint32_t rows = nblocks >> 3;
+    uint32_t pow2 = 1;
+    while (pow2 < rows) pow2 <<= 1;
+    if (pow2 > 8192u)
+        return fail(RF_ERR_INVALID_ARGUMENT, "rf_build_tile_orders: more than 65536 blocks (build the order on the host)");
+    OrderJob a{rule_a, param_a, order_a}, b{rule_b, param_b, order_b};
+    hipLaunchKernelGGL(tile_orders_kernel, dim3(8, order_b ? 2 : 1), dim3(256), (size_t)pow2 * sizeof(unsigned long long),
+                       static_cast<hipStream_t>(stream), tile_cost, num_rays, image_width, image_height, pow2, a, b);
+    return check_launch("rf_build_tile_orders");
+}
+
+static int prior_view(const char *who, const float *rays, const rf_camera *camera, uint32_t width, uint32_t height,
+                      PriorView &p) {
+    if ((rays == nullptr) == (camera == nullptr)) return fail(RF_ERR_INVALID_ARGUMENT, "%s: give the rays or the camera, not both", who);
+    p = PriorView{};
+    p.rays = rays;
+    if (camera) {
+        p.cam = *camera;
+        p.inv_tan_half_fov = 1.0f / tanf(0.5f * camera->fov);
+        width = camera->width;
+        height = camera->height;
+    }
+    if (width == 0 || height == 0) return fail(RF_ERR_INVALID_ARGUMENT, "%s: empty frame", who);
+    p.width = width;
+    p.height = height;
+    return RF_OK;
+}
+
+int rf_tile_order_reference(const float *rays, const rf_camera *camera, const uint32_t *start_point_index, const float *points,
+                            uint32_t image_width, uint32_t image_height, float *reference, void *stream) {
+    g_err[0] = 0;
+    if (!start_point_index || !points || !reference) return fail(RF_ERR_INVALID_ARGUMENT, "rf_tile_order_reference: null pointer");
+    PriorView v;
+    const int rc = prior_view("rf_tile_order_reference", rays, camera, image_width, image_height, v);
+    if (rc != RF_OK) return rc;
+    hipLaunchKernelGGL(tile_reference_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), v, start_point_index,
+                       points, reference);
+    return check_launch("rf_tile_order_reference");
+}
+
+int rf_gate_tile_order(const float *rays, const rf_camera *camera, const float *reference, uint32_t image_width,
+                       uint32_t image_height, float max_angle_radians, const uint32_t *learnt_order, uint32_t *order,
+                       uint32_t *verdict, void *stream) {
+    g_err[0] = 0;
+    if (!reference || !learnt_order || !order) return fail(RF_ERR_INVALID_ARGUMENT, "rf_gate_tile_order: null pointer");
+    PriorView v;
+    const int rc = prior_view("rf_gate_tile_order", rays, camera, image_width, image_height, v);
+    if (rc != RF_OK) return rc;
+    const uint32_t nblocks = launch_block_count(v.width * v.height, v.width, v.height);
+    hipLaunchKernelGGL(tile_order_gate_kernel, dim3((nblocks + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(stream), v,
+                       reference, max_angle_radians, learnt_order, order, verdict);
+    return check_launch("rf_gate_tile_order");
 }
 
 }  // extern "C"

@@ -268,18 +268,31 @@ class Pipeline:
         #: launches over a frame shape between two learnings of its tile orders when the rays keep changing (an order
         #: learnt on another camera of the same scene is worth as much as the frame's own: scripts/gpu_tile_order_stale.py)
         self.tile_order_refresh = 16
+        #: a frame the pipeline has NOT traced may take the forward / render order learnt on the previous frame of its
+        #: shape when the two show nearly the same picture -- a camera path (viewer, fly-through, bench.py's 0.05 degrees
+        #: per step): five sample rays of the two frames are compared ON THE DEVICE (rf_gate_tile_order: angle between
+        #: the directions + shift of the origin relative to its distance from the entry cell's point, every sample within
+        #: this many degrees; about one 16-pixel tile of a 1080p frame) and the launch gets the learnt order or the static
+        #: dealing accordingly, without a synchronisation.  Another camera of a data set fails the test and runs under the
+        #: static dealing as before (an order learnt on other rays is worse than it: profiles/r04/d_tile_order_*).  0: off.
+        self.tile_order_coherence_degrees = 0.5
+        #: renders (no backward follows) of rays that keep changing learn their order every this many launches
+        self.tile_order_refresh_render = 4
         #: image-shaped launches over rays the pipeline has NOT traced before (another camera: benchmark.py:95-139, a new
         #: training view): under "auto" the forward / render takes its block order from a cost PRIOR instead of the static
         #: dealing -- a coarse grid of the foam (cells per unit length, mean density per voxel: rf_build_cost_grid, rebuilt
         #: with the triangulation and every tile_prior_refresh geometry changes) marched by five rays per tile
         #: (rf_estimate_tile_cost), longest estimate first per XCD.  Needs no previous trace of these rays; results do
         #: not depend on it.  False: the static dealing for new rays (rounds 4-5).
-        self.tile_prior = True
+        self.tile_prior = False
         self.tile_prior_resolution = 32
         self.tile_prior_refresh = 64
         #: the rule applied to the estimated costs (see tile_order()); None = "xcd:8" for launches of at most 16384
         #: blocks (classes of 8 estimated steps, static order within a class), "tail" above
         self.tile_prior_rule = None
+        #: experiments only (scripts/gpu_tile_prior.py): an int32 device tensor that the next image-shaped forward / render
+        #: launches take as their block -> tile table, whatever the mode says
+        self.experiment_tile_order = None
         self._prior = None          # {"topo": key, "points": key, "grid": tensor, "age": geometry changes since it was built}
         self._prior_keep = None     # the order handed to the launch in flight
         self._defaults = {}         # (height, width, device) -> the static block -> tile table
@@ -690,7 +703,7 @@ class Pipeline:
             tiles_pending = self._tile_cost_begin(
                 opts, opts.image_height, opts.image_width, ray_keys[:2], dev, backward_follows=trail is not None,
                 prior={"rays": rays_c, "camera": None, "foam": (points_c, attributes_c, adjacency_c, offsets_c),
-                       "settings": settings})
+                       "settings": settings, "start": start_c})
         elif opts.ray_order:
             tiles_pending = self._tile_cost_begin(opts, "flat", num_rays, ray_keys[:2], dev)
         with torch.cuda.device(dev):
@@ -811,20 +824,34 @@ class Pipeline:
             t["age"] += 1
         if mode == "auto" and not same and height != "flat":
             # rays this pipeline has not traced: another camera's measured order does not transfer (the static dealing is
-            # better than it); the order a cost prior of THESE rays gives does (tile_prior)
+            # better than it) -- unless the frame is the next one of a camera path (tile_order_coherence_degrees: decided
+            # on the device); else the order a cost prior of THESE rays gives (tile_prior, off by default: measured out)
             opts.tile_order = None
             self._prior_keep = None
-            if self.tile_prior and prior is not None:
+            if known and t.get("ref") is not None and float(self.tile_order_coherence_degrees) > 0.0 and prior is not None:
+                order = torch.empty(t["forward"].numel(), dtype=torch.int32, device=dev)
+                cam = prior["camera"]
+                with torch.cuda.device(dev):
+                    rc = self._lib.rf_gate_tile_order(
+                        _ptr(prior["rays"]), C.byref(cam) if cam is not None else None, _ptr(t["ref"]), int(width),
+                        int(height), float(self.tile_order_coherence_degrees) * 0.017453292519943295, _ptr(t["forward"]),
+                        _ptr(order), _ptr(t["verdict"]), _stream_ptr(dev))
+                _lib.check(rc)
+                opts.tile_order = order.data_ptr()
+                self._prior_keep = order
+            elif self.tile_prior and prior is not None:
                 order = self._prior_tile_order(height, width, dev, prior)
                 opts.tile_order = order.data_ptr()
                 self._prior_keep = order
-        if known and (same or (t["age"] < int(self.tile_order_refresh) and not (mode == "auto" and backward_follows and
-                                                                                  height != "flat"))):
+        if self.experiment_tile_order is not None and height != "flat":
+            opts.tile_order = self.experiment_tile_order.data_ptr()
+        refresh = int(self.tile_order_refresh if (backward_follows or height == "flat") else self.tile_order_refresh_render)
+        if known and (same or (t["age"] < refresh and not (mode == "auto" and backward_follows and height != "flat"))):
             return None
         tiles = (width + 255) // 256 if height == "flat" else ((height + 15) // 16) * ((width + 15) // 16)
         cost = torch.zeros(tiles, dtype=torch.int32, device=dev)
         opts.tile_cost = cost.data_ptr()
-        return (height, width, key, cost)
+        return (height, width, key, cost, prior)
 
     def _tile_cost_end(self, pending):
         """Tile orders for the next launches over a frame of this shape (all on the device, no synchronisation): a tile
@@ -832,7 +859,7 @@ class Pipeline:
         the same frame shape meanwhile: any order is correct."""
         if pending is None:
             return
-        height, width, key, cost = pending
+        height, width, key, cost, prior = pending
         mode = self.tile_order_mode
         dev = cost.device
         t = self._tile_sets.get((height, width))
@@ -849,13 +876,62 @@ class Pipeline:
             rules = ("tail:%d" % max(8, int(cost.numel()) // 8),) * 2
         else:
             rules = ("xcd" if default.numel() <= 16384 else "tail", "tail")
-        orders = {rule: tile_order(cost, default, rule).to(torch.int32).contiguous() for rule in set(rules)}
-        t.update(key=key, mode=mode, age=0, forward=orders[rules[0]], backward=orders[rules[1]])
+        orders = self._build_orders(cost, default, height, width, rules)
+        t.update(key=key, mode=mode, age=0, forward=orders[0], backward=orders[1])
+        # what a later frame is compared with before it may borrow this frame's order (rf_gate_tile_order)
+        if height != "flat" and prior is not None and prior.get("start") is not None:
+            ref = t.get("ref")
+            if ref is None or ref.device != dev:
+                ref = torch.empty(40, dtype=torch.float32, device=dev)
+                t["verdict"] = torch.zeros(1, dtype=torch.int32, device=dev)
+            cam = prior["camera"]
+            with torch.cuda.device(dev):
+                rc = self._lib.rf_tile_order_reference(
+                    _ptr(prior["rays"]), C.byref(cam) if cam is not None else None, _ptr(prior["start"]),
+                    _ptr(prior["foam"][0]), int(width), int(height), _ptr(ref), _stream_ptr(dev))
+            _lib.check(rc)
+            t["ref"] = ref
+        else:
+            t["ref"] = None
         self._tile_sets.pop((height, width), None)
         while len(self._tile_sets) >= 8:                    # a handful of frame shapes at most
             self._tile_sets.pop(next(iter(self._tile_sets)))
         self._tile_sets[(height, width)] = t
         self._tiles = t
+
+    @staticmethod
+    def _device_rule(rule):
+        """(rule id, parameter) of rf_build_tile_orders for a tile_order() rule it implements, else None."""
+        if rule == "xcd":
+            return 1, 1
+        if rule.startswith("xcd:"):
+            return 1, max(1, int(rule.split(":")[1]))
+        if rule == "tail":
+            return 2, 2048
+        if rule.startswith("tail:"):
+            return 2, max(1, int(rule.split(":")[1]))
+        return None
+
+    def _build_orders(self, cost, default, height, width, rules):
+        """The two block -> tile tables (forward, backward) of `rules` from a cost map: one launch of rf_build_tile_orders
+        (rounds 4-5: two dozen torch operations, 0.2-0.25 ms on the launch stream after every forward that learnt); the
+        torch path remains for the experiment rules ("global", "chunk:n") and for launches beyond 65536 blocks."""
+        dev = cost.device
+        nb = int(default.numel())
+        dr = [self._device_rule(r) for r in rules]
+        if all(r is not None for r in dr) and nb <= 65536:
+            a = torch.empty(nb, dtype=torch.int32, device=dev)
+            b = a if rules[1] == rules[0] else torch.empty(nb, dtype=torch.int32, device=dev)
+            flat = height == "flat"
+            num_rays = int(width) if flat else int(height) * int(width)
+            with torch.cuda.device(dev):
+                rc = self._lib.rf_build_tile_orders(
+                    _ptr(cost), num_rays, 0 if flat else int(width), 0 if flat else int(height), dr[0][0], dr[0][1], _ptr(a),
+                    dr[1][0], dr[1][1], None if b is a else _ptr(b), _stream_ptr(dev))
+            _lib.check(rc)
+            return a, b
+        made = {rule: tile_order(cost, default, rule).to(torch.int32).contiguous() for rule in set(rules)}
+        return made[rules[0]], made[rules[1]]
 
     # -- trace_backward --------------------------------------------------------------------------
     def trace_backward(self, points, attributes, point_adjacency, point_adjacency_offsets, rays,
@@ -1052,7 +1128,8 @@ class Pipeline:
         cam_key = ("camera", bytes(cam), self._tkey(start_point))
         tiles_pending = self._tile_cost_begin(
             opts, cam.height, cam.width, cam_key, dev,
-            prior={"rays": None, "camera": cam, "foam": (points_c, attributes_c, adjacency_c, offsets_c), "settings": settings})
+            prior={"rays": None, "camera": cam, "foam": (points_c, attributes_c, adjacency_c, offsets_c), "settings": settings,
+                   "start": start_point})
         with torch.cuda.device(dev):
             rc = self._lib.rf_trace_benchmark(
                 self._sh_degree, self._attr_type, C.byref(settings), num_points, _ptr(points_c),

@@ -72,20 +72,44 @@ g = torch.randn((H, W, 4), generator=torch.Generator().manual_seed(1)).to(dev)
 ev = lambda: torch.cuda.Event(enable_timing=True)
 
 
+def measured_orders(rule="xcd"):
+    """Per view: the block -> tile table its OWN measured tile costs give (forward and render), computed ahead of time."""
+    from radfoam_amd.pipeline import tile_order
+    pipe = radfoam.create_pipeline(2)
+    default = pipe._default_tiles(H, W, dev)
+    out = []
+    for rays, start, cam, sp in frames:
+        ni = pipe.trace_forward(p, a, adj, off, rays, start)["num_intersections"].reshape(H, W).to(torch.int32)
+        pad = torch.nn.functional.pad(ni, (0, (-W) % 16, 0, (-H) % 16))
+        cost = pad.view(pad.shape[0] // 16, 16, pad.shape[1] // 16, 16).amax(dim=(1, 3)).reshape(-1)
+        out.append(tile_order(cost, default, rule).to(torch.int32).contiguous())
+    return out
+
+
 def run(mode, rule=None, res=32):
-    """mode: static | prior | own (every view traced twice, the second pass timed: its own measured order)."""
+    """mode: static | prior | own (every view traced twice, the second pass timed: its own measured order, caches warm) |
+    static-warm (every view twice under the static dealing, the second pass timed: what the caches alone are worth) |
+    own-cold (the view's own measured order, computed ahead of time, on a view traced ONCE after other views: what the
+    order alone is worth)."""
     pipe, rend = radfoam.create_pipeline(2), radfoam.create_pipeline(2, torch.float16)
+    orders = measured_orders() if mode == "own-cold" else None
     for q in (pipe, rend):
         q.record_trail = True
         q.tile_prior = mode == "prior"
         q.tile_prior_rule = rule
         q.tile_prior_resolution = res
+        if mode in ("static", "static-warm", "own-cold"):
+            q.tile_order_mode = None if mode != "own-cold" else "auto"
+        if mode != "auto":
+            q.tile_order_coherence_degrees = 0.0      # (the modes of rounds 4-5; "auto" = the pipeline's defaults of round 6)
     diff = rend.build_adjacent_diff(p, adj, off)
     out8 = torch.zeros((H, W), dtype=torch.uint32, device=dev)
     t = {"forward": [], "backward": [], "render": []}
     for rnd in range(3):                                   # round 0 warms up
-        for rays, start, cam, sp in frames:
-            for rep in range(2 if mode == "own" else 1):
+        for vi, (rays, start, cam, sp) in enumerate(frames):
+            if orders is not None:
+                pipe.experiment_tile_order = rend.experiment_tile_order = orders[vi]
+            for rep in range(2 if mode in ("own", "static-warm") else 1):
                 e = [ev() for _ in range(4)]
                 e[0].record()
                 f = pipe.trace_forward(p, a, adj, off, rays, start)
@@ -95,7 +119,7 @@ def run(mode, rule=None, res=32):
                 rend.trace_benchmark(p, a16, adj, off, diff, cam, sp, out8, weight_threshold=0.05)
                 e[3].record()
                 torch.cuda.synchronize()
-                if rnd and rep == (1 if mode == "own" else 0):
+                if rnd and rep == (1 if mode in ("own", "static-warm") else 0):
                     for k, name in enumerate(("forward", "backward", "render")):
                         t[name].append(e[k].elapsed_time(e[k + 1]))
     return {k: {"mean_ms": round(float(np.mean(v)), 4), "worst_ms": round(float(np.max(v)), 4)} for k, v in t.items()}
@@ -126,7 +150,10 @@ res = {"scene": "asymmetric density on the north-star points, tilted orbit" if a
        "north-star frame, camera path of 0.05 degrees per view", "views": args.views, "rank": {}, "modes": {}}
 for r in args.res:
     res["rank"][str(r)] = rank_quality(r)
+res["modes"]["auto"] = run("auto")
 res["modes"]["static"] = run("static")
+res["modes"]["static-warm"] = run("static-warm")
+res["modes"]["own-cold"] = run("own-cold")
 res["modes"]["own"] = run("own")
 for r in args.res:
     for rule in args.rules:

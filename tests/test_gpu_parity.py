@@ -1217,3 +1217,101 @@ def test_tile_prior_ranks_tiles_and_does_not_change_results(foam_factory):
         assert (rend._prior_keep is not None) == prior
     np.testing.assert_array_equal(words[True], words[False])
     assert words[True].any()
+
+
+def test_device_built_tile_orders_equal_the_host_rules():
+    """rf_build_tile_orders (one launch, per-XCD bitonic sort in LDS) against radfoam_amd.pipeline.tile_order (the torch
+    restatement rounds 4-5 ran after every learning forward): the same table entry for entry, for the rules "auto" uses and
+    their parameters, on frames whose last round of blocks is padding and on a flat batch -- ties, a cost map with many
+    equal entries and tiles beyond the histogram's last bin included."""
+    import ctypes as C
+    from radfoam_amd import _lib
+    from radfoam_amd.pipeline import Pipeline, tile_order
+
+    lib = _lib.load()
+    pipe = _pipeline(0)
+    gen = torch.Generator().manual_seed(4)
+    for (h, w) in ((1080, 1920), (136, 200), (2160, 3840), ("flat", 1_000_000)):
+        default = pipe._default_tiles(h, w, torch.device(DEV))
+        nt = (w + 255) // 256 if h == "flat" else ((h + 15) // 16) * ((w + 15) // 16)
+        for kind in ("spread", "ties", "huge"):
+            cost = torch.randint(1, 300, (nt,), generator=gen, dtype=torch.int32)
+            if kind == "ties":
+                cost = (cost // 40) * 40
+            if kind == "huge":
+                cost[::7] += 6000
+            cost = cost.to(DEV)
+            for rules in (("xcd", "tail"), ("xcd:8", "tail:7"), ("tail:%d" % max(8, nt // 8),) * 2):
+                a, b = pipe._build_orders(cost, default, h, w, rules)
+                for got, rule in ((a, rules[0]), (b, rules[1])):
+                    want = tile_order(cost, default, rule)
+                    # tiles past the end keep SOME value >= nt in both (which one is immaterial: the block owns no rays)
+                    g64, w64 = got.to(torch.int64).clamp(max=nt), want.clamp(max=nt)
+                    assert torch.equal(g64, w64), (h, w, kind, rule)
+    with pytest.raises(RuntimeError, match="rule must be"):
+        out = torch.empty(64, dtype=torch.int32, device=DEV)
+        _lib.check(lib.rf_build_tile_orders(C.c_void_p(out.data_ptr()), 256 * 64, 0, 0, 9, 1, C.c_void_p(out.data_ptr()), 0, 0,
+                                            None, None))
+
+
+def test_a_camera_path_borrows_the_previous_frames_order_and_another_camera_does_not(foam_factory):
+    """Pipeline.tile_order_coherence_degrees: the next frame of a camera path (0.05 degrees on) takes
+    the forward order the previous frame's trace measured -- decided on the device by rf_gate_tile_order from five sample
+    rays, no synchronisation --, a camera 40 degrees away fails the test and runs under the static dealing; either way the
+    outputs are the oracle's, bit for bit.  Same through trace_benchmark's camera."""
+    import bench
+    import radfoam
+    from radfoam_amd import foam
+
+    d = 1
+    fm = foam_factory(20000, d, 19)
+    p, a, adj, off = H.to_torch_foam(fm, DEV)
+    pipe = _pipeline(d)
+    args = (d, fm["points"], fm["attributes"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    W_, H_ = 320, 208
+
+    def view(k):
+        cam = bench.view_camera(W_, H_, 0, k)
+        rays = foam.camera_rays(cam)
+        return cam, rays, np.uint32(foam.nearest_point(fm["points"], cam["position"]))
+
+    verdicts = []
+    for k in (0, 1, 2, 800):                # 0.05 degrees per view; view 800 is 40 degrees on
+        cam, rays, start = view(k)
+        ref = O.trace_forward(*args, rays, start)
+        got, _ = _run_forward(pipe, fm, rays, start)
+        np.testing.assert_array_equal(got["rgba"].numpy().view(np.uint32), ref["rgba"].view(np.uint32))
+        np.testing.assert_array_equal(got["num_intersections"].numpy().view(np.uint32), ref["num_intersections"])
+        t = pipe._tiles
+        if k:
+            order = pipe._prior_keep
+            assert order is not None
+            coherent = int(t["verdict"].item())
+            verdicts.append(coherent)
+            default = pipe._default_tiles(H_, W_, torch.device(DEV)).to(torch.int32)
+            assert torch.equal(order, prev_forward if coherent else default)
+        prev_forward = t["forward"].clone()
+    assert verdicts == [1, 1, 0]
+    pipe.tile_order_coherence_degrees = 0.0     # off: new rays run under the static dealing, no gate
+    cam, rays, start = view(3)
+    _run_forward(pipe, fm, rays, start)
+    assert pipe._prior_keep is None
+    # the render path: the camera instead of a ray tensor (learns every tile_order_refresh_render launches)
+    rend = radfoam.create_pipeline(d, torch.float16)
+    rend.tile_order_refresh_render = 1
+    a16 = a.to(torch.float16)
+    diff = rend.build_adjacent_diff(p, adj, off)
+    hdiff = O.build_adjacent_diff(fm["points"], fm["point_adjacency"], fm["point_adjacency_offsets"])
+    verdicts = []
+    for k in (0, 1, 800):
+        cam, rays, start = view(k)
+        out8 = torch.zeros((H_, W_), dtype=torch.uint32, device=DEV)
+        camt = {kk: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for kk, v in cam.items()}
+        rend.trace_benchmark(p, a16, adj, off, diff, camt, torch.tensor([int(start)], dtype=torch.int64).to(torch.uint32).to(DEV),
+                             out8, weight_threshold=0.05)
+        want = O.trace_benchmark(d, fm["points"], fm["attributes"].astype(np.float16), fm["point_adjacency"],
+                                 fm["point_adjacency_offsets"], hdiff, cam, start, weight_threshold=0.05)
+        np.testing.assert_array_equal(out8.cpu().numpy().view(np.uint32), want)
+        if k:
+            verdicts.append(int(rend._tiles["verdict"].item()))
+    assert verdicts == [1, 0]
