@@ -263,6 +263,9 @@ struct __attribute__((aligned(8))) GeoZ {
 // cross-multiplied tournament WITHOUT the certificate, i.e. near-ties decided by the rounded products) and this one only
 // as the dividing instance; profiles/HISTORY.md has its numbers.
 constexpr uint32_t kTieUlps = 3;    // see above; must stay below scan_block's bias (64)
+#ifndef RF_RESOLVE_BY_DIVIDING_ALL
+#define RF_RESOLVE_BY_DIVIDING_ALL 0   // 1: contested cells rescanned by scan_faces_strict (rounds 5's resolution; A/B)
+#endif
 
 __device__ __forceinline__ void load_geo_block(const uint32_t *src, GeoXY &A, GeoZ &B) {
     A = *reinterpret_cast<const GeoXY *>(src);
@@ -365,8 +368,11 @@ __device__ __forceinline__ void scan_block(ScanState &S, uint32_t k, unsigned lo
 __device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uint32_t cnt, float Px, float Py, float Pz,
                                                         float Ox, float Oy, float Oz, float dx, float dy, float dz);
 
-// what a finished tournament found; `contested`: some comparison was too close for the products to decide
-__device__ __forceinline__ ScanResult scan_end(const ScanState &S, bool &contested) {
+__device__ __forceinline__ ScanResult scan_resolve(const uint16_t *blk, uint32_t cnt, const ScanState &S, const ScanRay &R);
+
+// what a finished tournament found; `contested`: some comparison was too close for the products to decide; `strict`: the
+// products cannot be trusted at all for this cell (see the fail-safe below) -- only the dividing scan may decide it
+__device__ __forceinline__ ScanResult scan_end(const ScanState &S, bool &contested, bool &strict) {
     ScanResult r;
     const bool found = S.blk != kNone;
     const uint32_t pos = (__builtin_amdgcn_inverse_ballot_w64(S.b1) ? 2u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(S.b0) ? 1u : 0u);
@@ -381,6 +387,56 @@ __device__ __forceinline__ ScanResult scan_end(const ScanState &S, bool &contest
     // at most theirs in magnitude class, so looking at the winner's exponent field is enough: zero => the dividing scan decides.
     const bool tiny = found && (__builtin_bit_cast(uint32_t, r.t1) & 0x7F800000u) == 0u;
     contested = (S.tie <= kTieUlps) | tiny;
+    strict = tiny | !found | (r.k == kNone);
+    return r;
+}
+
+// A contested cell -- some comparison of the tournament was within kTieUlps floats -- does not need every face divided
+// (scan_faces_strict: ~450 VALU with 20 IEEE divides, under divergence: 2.3 % of the wave-steps of a frame wait behind one
+// lane's rescan).  Whatever the close comparisons did to the tournament, its winner W is SOME face
+// with dp > 0, so the reference's exit -- the smallest rounded quotient, the first among equals -- has a rounded quotient
+// <= W's.  One certified comparison per face against W (the same products and bit distance as in the tournament) drops every
+// face whose rounded quotient is STRICTLY larger than W's; what is left -- W itself, faces within kTieUlps floats of it and
+// faces the products order before it -- is divided, in list order, with the reference's strict '<': the reference's loop
+// restricted to the only faces that can win it.  Typically two or three divides instead of twenty.
+__device__ __forceinline__ ScanResult scan_resolve(const uint16_t *blk, uint32_t cnt, const ScanState &S, const ScanRay &R) {
+    ScanResult r;
+    r.t1 = __builtin_inff();
+    r.k = kNone;
+    const v2f zero2 = {0.0f, 0.0f};
+    const v2f nw = {S.best.y, S.best.y}, dw = {S.best.x, S.best.x};    // the winner's num and dp, in both halves
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(blk);
+    for (uint32_t k = 0; k < cnt; k += 4) {
+        GeoXY A;
+        GeoZ B;
+        load_geo_block(src, A, B);
+        src += 6;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v2f num, dpp;
+            face_pair(h ? A.x23 : A.x01, h ? A.y23 : A.y01, h ? B.z23 : B.z01, R, num, dpp);
+            const v2f pf = fma2(num, dw, zero2);        // num_face * dp_W
+            const v2f pw = fma2(nw, dpp, zero2);        // num_W * dp_face
+            // certainly behind the winner: the products say so by more than kTieUlps floats
+            const bool far0 = (pf.x > pw.x) & (bit_distance(pf.x, pw.x, 0u) > kTieUlps);
+            const bool far1 = (pf.y > pw.y) & (bit_distance(pf.y, pw.y, 0u) > kTieUlps);
+            const bool c0 = (dpp.x > 0.0f) & !far0, c1 = (dpp.y > 0.0f) & !far1;
+            if (c0) {
+                const float t = num.x / dpp.x;
+                if (t < r.t1) {
+                    r.t1 = t;
+                    r.k = k + (uint32_t)(2 * h);
+                }
+            }
+            if (c1) {
+                const float t = num.y / dpp.y;
+                if (t < r.t1) {
+                    r.t1 = t;
+                    r.k = k + (uint32_t)(2 * h + 1);
+                }
+            }
+        }
+    }
     return r;
 }
 
@@ -411,9 +467,12 @@ __device__ __forceinline__ ScanResult scan_faces(const uint16_t *blk, uint32_t c
             act = ballot(k < cnt);
         } while (act != 0ull);
     }
-    bool contested;
-    ScanResult r = scan_end(S, contested);
-    if (contested) r = scan_faces_strict(blk, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
+    bool contested, strict;
+    ScanResult r = scan_end(S, contested, strict);
+    if (contested) {
+        if (RF_RESOLVE_BY_DIVIDING_ALL || strict) r = scan_faces_strict(blk, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
+        else r = scan_resolve(blk, cnt, S, R);
+    }
     return r;
 }
 
@@ -458,9 +517,12 @@ __device__ __forceinline__ ScanResult scan_faces_eager(const GeoBlocks<K> &G, co
         k += 4;
         act = ballot(k < cnt);
     }
-    bool contested;
-    ScanResult r = scan_end(S, contested);
-    if (contested) r = scan_faces_strict(blk, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
+    bool contested, strict;
+    ScanResult r = scan_end(S, contested, strict);
+    if (contested) {
+        if (RF_RESOLVE_BY_DIVIDING_ALL || strict) r = scan_faces_strict(blk, cnt, Px, Py, Pz, Ox, Oy, Oz, dx, dy, dz);
+        else r = scan_resolve(blk, cnt, S, R);
+    }
     return r;
 }
 
