@@ -45,6 +45,9 @@ ap.add_argument("--forward-mode", type=int, default=0, help="Pipeline.forward_mo
 ap.add_argument("--batch", action="store_true", help="the data-parallel training step on the train-batch-lit workload (see above)")
 ap.add_argument("--rays", type=int, default=1_000_000)
 ap.add_argument("--quantiles", type=int, default=0)
+ap.add_argument("--shards", choices=["index", "sorted"], default="index",
+                help="--batch: a rank's share = a 1/W slice of the shuffled batch (what BatchFetcher(rank=, world_size=) serves) "
+                     "or of the batch in the kernels' coherent order")
 args = ap.parse_args()
 if args.batch and args.sh_degree == 2:
     args.sh_degree = 3          # the training batch of bench.py is SH 3
@@ -120,11 +123,35 @@ def simulate_training_batch():
     del flat
     torch.cuda.empty_cache()
     out["replicated_per_rank_ms"] = {"adam_step": round(t_adam, 4), "nonfinite_scrub_of_the_flat_buffer": round(t_scrub, 4)}
+    # --shards sorted: rank r takes a contiguous 1/W of the batch in the kernels' own coherent order (entry cell, then
+    # direction: rf_build_ray_order over the WHOLE batch, which every rank would compute for itself) instead of a 1/W of
+    # the batch as it was shuffled -- its rays are then neighbours (one patch of one camera's directions) instead of a
+    # 1/W-dense sample of every camera
+    order = None
+    if args.shards == "sorted":
+        import ctypes as C
+        from radfoam_amd import _lib
+        lib = _lib.load()
+        order = torch.empty(args.rays, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(int(lib.rf_ray_order_workspace_bytes(args.rays)), 256), dtype=torch.uint8, device=dev)
+
+        def sort_batch():
+            _lib.check(lib.rf_build_ray_order(C.c_void_p(rays.data_ptr()), C.c_void_p(start.data_ptr()), args.rays,
+                                              C.c_void_p(order.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+
+        out["replicated_per_rank_ms"]["ray_order_of_the_whole_batch"] = round(timed(sort_batch), 4)
+        order = order.to(torch.int64)
+        t_take = timed(lambda: (rays[order[: args.rays // 8]], start[order[: args.rays // 8]]))
+        out["replicated_per_rank_ms"]["gather_of_a_rank_share_at_world_8"] = round(t_take, 4)
+    out["shards"] = args.shards
     for world in args.worlds:
         per = args.rays // world
         ranks = []
         for r in range(world):
             sl = slice(r * per, (r + 1) * per)
+            if order is not None:
+                sl = order[sl]
             rr, ss, gg = rays[sl].contiguous(), start[sl].contiguous(), (g[sl] * (1.0 / world)).contiguous()
             qq = None if q is None else q[sl].contiguous()
             dd = None if dg is None else (dg[sl] * (1.0 / world)).contiguous()
