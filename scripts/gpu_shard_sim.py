@@ -142,7 +142,8 @@ def simulate_training_batch():
 
         out["replicated_per_rank_ms"]["ray_order_of_the_whole_batch"] = round(timed(sort_batch), 4)
         order = order.to(torch.int64)
-        t_take = timed(lambda: (rays[order[: args.rays // 8]], start[order[: args.rays // 8]]))
+        start_i = start.view(torch.int32)        # (uint32 tensors cannot be indexed on the device: the words as int32)
+        t_take = timed(lambda: (rays[order[: args.rays // 8]], start_i[order[: args.rays // 8]]))
         out["replicated_per_rank_ms"]["gather_of_a_rank_share_at_world_8"] = round(t_take, 4)
     out["shards"] = args.shards
     for world in args.worlds:
@@ -152,7 +153,8 @@ def simulate_training_batch():
             sl = slice(r * per, (r + 1) * per)
             if order is not None:
                 sl = order[sl]
-            rr, ss, gg = rays[sl].contiguous(), start[sl].contiguous(), (g[sl] * (1.0 / world)).contiguous()
+            rr, ss, gg = rays[sl].contiguous(), start.view(torch.int32)[sl].contiguous().view(torch.uint32), \
+                (g[sl] * (1.0 / world)).contiguous()
             qq = None if q is None else q[sl].contiguous()
             dd = None if dg is None else (dg[sl] * (1.0 / world)).contiguous()
             state = {}

@@ -184,10 +184,20 @@ def _worker(rank, world, port, shard, exchange, out_dir):
         rdist.enable_data_parallel(shard_batches=(shard == "caller"), shard=shard, exchange=exchange)
         assert shims.BatchFetcher.default_shard == ((rank, world) if shard == "caller" else None)
         radfoam.create_pipeline = lambda d, dt="float32": rdist.wrap_pipeline(OraclePipeline(d))
+        if shard == "rows":     # flat batches cut in the coherent order (normally from 16384 rays on)
+            keep_init = rdist.DataParallelPipeline.__init__
+
+            def small_batches_too(self, *a, **k):
+                keep_init(self, *a, **k)
+                self.coherent_min_rays = 64
+
+            rdist.DataParallelPipeline.__init__ = small_batches_too
         res = train_steps(scene_mod, steps=3, batch=512, shard=shard)
         model = res["model"]
         pipe = model.pipeline
         assert isinstance(pipe, rdist.DataParallelPipeline) and pipe.last_exchange["world"] == world
+        if shard == "rows":
+            assert pipe._cut is not None and pipe._cut["rays"].shape == (256, 6)      # the sorted cut was taken
         assert pipe.last_exchange["exchange"] == ("dense" if exchange in ("auto", "dense") else pipe.last_exchange["exchange"])
         pipe.backward_mode = 4                                  # a knob lands on the wrapped pipeline
         assert pipe.inner.backward_mode == 4 and "backward_mode" not in pipe.__dict__
@@ -329,7 +339,7 @@ def _loop_worker(rank, world, port, out_dir):
     import radfoam
     from examples import train_loop
     from radfoam_amd import dist as rdist
-    from radfoam_amd import foam
+    from radfoam_amd import foam, shims
 
     if world > 1:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -341,6 +351,7 @@ def _loop_worker(rank, world, port, out_dir):
         its, detail = train_loop.run(None, env, fm, sh_degree=1, iterations=5, rays_per_batch=1536, cameras=2, width=48,
                                      height=32, densify_at=10 ** 9)
         assert detail["world_size"] == world and detail["rays_per_rank"] == 1536 // world
+        assert shims.BatchFetcher.default_shard is None
         if world > 1:
             assert detail["last_exchange"]["exchange"] == "dense" and detail["calls_by_section"]["replica_check"] >= 2
             assert detail["calls_by_section"]["tracer_backward_kernels"] == 5
@@ -373,3 +384,26 @@ def test_train_loop_example_runs_data_parallel_on_cpu_ranks(tmp_path):
     assert [i for i, _ in r0["losses"]] == [i for i, _ in one["losses"]]
     mean = [0.5 * (a[1] + b[1]) for a, b in zip(r0["losses"], r1["losses"])]
     np.testing.assert_allclose(mean, [l for _, l in one["losses"]], rtol=2e-4)
+
+
+def test_coherent_shards_partition_a_batch_by_camera_and_direction():
+    """dist.coherent_shard: a rank's share of a flat batch that every rank holds whole is a contiguous slice of the batch
+    sorted by camera (origin) and direction -- the shares partition the batch, each holds rays of as few cameras as its
+    size allows, and the order is a pure function of the rays (every rank computes the same one)."""
+    from radfoam_amd import dist as rdist
+    g = torch.Generator().manual_seed(1)
+    cams = torch.tensor([[0.0, 0.0, -3.0], [2.0, 1.0, 0.5], [-1.0, 2.0, 2.0], [0.5, -2.5, 1.0]])
+    which = torch.randint(0, 4, (4096,), generator=g)
+    rays = torch.cat([cams[which], torch.nn.functional.normalize(torch.randn(4096, 3, generator=g), dim=1)], dim=1)
+    shares = [rdist.coherent_shard(rays, r, 8) for r in range(8)]
+    assert sorted(torch.cat(shares).tolist()) == list(range(4096))
+    assert all(s.numel() == 512 for s in shares)
+    assert torch.equal(rdist.coherent_order(rays), rdist.coherent_order(rays.clone()))
+    # 4 cameras of ~1024 rays over 8 shares of 512: a share spans at most 2 cameras (an index share holds all 4)
+    assert max(len(set(which[s].tolist())) for s in shares) <= 3
+    assert len(set(which[:512].tolist())) == 4
+    # an explicit group key (the entry cell) takes the place of the origin hash
+    o = rdist.coherent_order(rays, which.to(torch.int64).to(torch.uint32))
+    assert (which[o][1:] >= which[o][:-1]).all()
+    with pytest.raises(RuntimeError, match="multiple of the world size"):
+        rdist.coherent_shard(rays[:4095], 0, 8)
