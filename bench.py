@@ -66,7 +66,7 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3  # 256 CUs x 128 FMA lanes x 2 flop x 2.4 GHz (s
 # made from other sources.
 SCAN_VALU_PER_4_FACES = 67
 SCAN_FLOP_PER_4_FACES = 92
-HOP_VALU_PER_LANE = 92
+HOP_VALU_PER_LANE = 84      # (round 5 quoted 92: it counted the statically inlined preamble of the contested cells' rescan)
 COMPOSITE_VALU_PER_LANE = 61
 
 

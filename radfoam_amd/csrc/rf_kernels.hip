@@ -263,6 +263,14 @@ struct __attribute__((aligned(8))) GeoZ {
 // cross-multiplied tournament WITHOUT the certificate, i.e. near-ties decided by the rounded products) and this one only
 // as the dividing instance; profiles/HISTORY.md has its numbers.
 constexpr uint32_t kTieUlps = 3;    // see above; must stay below scan_block's bias (64)
+#ifndef RF_OUTLINE_RESCANS
+#define RF_OUTLINE_RESCANS 0           // 1: the rescans of contested cells as real functions (a call) instead of inlined code
+#endif
+#if RF_OUTLINE_RESCANS
+#define RF_RESCAN_FN __device__ __attribute__((noinline))
+#else
+#define RF_RESCAN_FN __device__ __forceinline__
+#endif
 #ifndef RF_RESOLVE_BY_DIVIDING_ALL
 #define RF_RESOLVE_BY_DIVIDING_ALL 0   // 1: contested cells rescanned by scan_faces_strict (rounds 5's resolution; A/B)
 #endif
@@ -365,10 +373,10 @@ __device__ __forceinline__ void scan_block(ScanState &S, uint32_t k, unsigned lo
     S.blk = __builtin_amdgcn_inverse_ballot_w64(any) ? k : S.blk;
 }
 
-__device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uint32_t cnt, float Px, float Py, float Pz,
+RF_RESCAN_FN ScanResult scan_faces_strict(const uint16_t *blk, uint32_t cnt, float Px, float Py, float Pz,
                                                         float Ox, float Oy, float Oz, float dx, float dy, float dz);
 
-__device__ __forceinline__ ScanResult scan_resolve(const uint16_t *blk, uint32_t cnt, const ScanState &S, const ScanRay &R);
+RF_RESCAN_FN ScanResult scan_resolve(const uint16_t *blk, uint32_t cnt, const ScanState &S, const ScanRay &R);
 
 // what a finished tournament found; `contested`: some comparison was too close for the products to decide; `strict`: the
 // products cannot be trusted at all for this cell (see the fail-safe below) -- only the dividing scan may decide it
@@ -388,6 +396,12 @@ __device__ __forceinline__ ScanResult scan_end(const ScanState &S, bool &contest
     const bool tiny = found && (__builtin_bit_cast(uint32_t, r.t1) & 0x7F800000u) == 0u;
     contested = (S.tie <= kTieUlps) | tiny;
     strict = tiny | !found | (r.k == kNone);
+#ifdef RF_ISA_NO_CONTESTED_PATH
+    // scripts/isa_stats.py --constants only (never shipped: results would be wrong): the rescans of contested cells compiled
+    // out, so that the instructions counted per hop are those of a wave-step in which no lane is contested (97.7 % of them)
+    // and not the statically inlined preambles of scan_resolve / scan_faces_strict
+    contested = false;
+#endif
     return r;
 }
 
@@ -399,7 +413,7 @@ __device__ __forceinline__ ScanResult scan_end(const ScanState &S, bool &contest
 // face whose rounded quotient is STRICTLY larger than W's; what is left -- W itself, faces within kTieUlps floats of it and
 // faces the products order before it -- is divided, in list order, with the reference's strict '<': the reference's loop
 // restricted to the only faces that can win it.  Typically two or three divides instead of twenty.
-__device__ __forceinline__ ScanResult scan_resolve(const uint16_t *blk, uint32_t cnt, const ScanState &S, const ScanRay &R) {
+RF_RESCAN_FN ScanResult scan_resolve(const uint16_t *blk, uint32_t cnt, const ScanState &S, const ScanRay &R) {
     ScanResult r;
     r.t1 = __builtin_inff();
     r.k = kNone;
@@ -603,7 +617,7 @@ __device__ __forceinline__ void cache_fill(CellEntry<K> *cache, uint32_t entries
 // scans above, and is selectable for whole launches as rf_launch_opts.forward_mode = 3 -- the independent instance the
 // filtered scan is tested against bit for bit (tests/test_gpu_parity.py); a correctly rounded divide per face makes it
 // 40 % slower on a frame.
-__device__ __forceinline__ ScanResult scan_faces_strict(const uint16_t *blk, uint32_t cnt, float Px, float Py, float Pz,
+RF_RESCAN_FN ScanResult scan_faces_strict(const uint16_t *blk, uint32_t cnt, float Px, float Py, float Pz,
                                                         float Ox, float Oy, float Oz, float dx, float dy, float dz) {
     ScanResult r;
     r.t1 = __builtin_inff();
