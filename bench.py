@@ -305,7 +305,11 @@ def main():
     if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the tracer has no CPU path")
-        dev = torch.device("cuda", local_rank)
+        ndev = torch.cuda.device_count()
+        if local_rank >= ndev and args.backend == "nccl":
+            raise SystemExit(f"bench.py: rank {local_rank} has no GPU of its own ({ndev} visible); RCCL needs one device per "
+                             "rank (--backend gloo shares them: a functional run, not a measurement)")
+        dev = torch.device("cuda", local_rank % ndev)
         torch.cuda.set_device(dev)     # before the process group: RCCL binds its communicator to the current device
     else:
         dev = torch.device("cpu")
@@ -315,7 +319,8 @@ def main():
         kw = {"device_id": dev} if (on_gpu and args.backend == "nccl") else {}
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
 
-    env = dict(torch=torch, dist=dist, world=world, rank=rank, dev=dev, on_gpu=on_gpu, test_factory=test_factory)
+    env = dict(torch=torch, dist=dist, world=world, rank=rank, dev=dev, on_gpu=on_gpu, test_factory=test_factory,
+               shared_gpus=bool(on_gpu and world > torch.cuda.device_count()))
     W = resolve_workload(args)
     result = run_train_loop(args, W, env) if W["kind"] == "loop" else run_workload(args, W, env)
     if result is not None and on_gpu and world == 1 and args.workload == "north-star" and not W.get("custom") and \
@@ -371,7 +376,9 @@ def run_train_loop(args, W, env):
         "metric": f"training iterations/s, {W['label']}",
         "value": round(its, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": 0,
         "ms_per_step": detail["wall_ms_per_iteration"], "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if not env.get("shared_gpus") else
+                "synthetic (the ranks SHARE GPUs under gloo: a functional run of the data-parallel loop, not a measurement)",
         "config": {
             "workload": f"{W['label']}: the reference's unmodified RadFoamScene + TraceRays (radfoam_model/scene.py, "
                         f"render.py) on a synthetic {W['points']}-point foam (seed {W['seed']}), SH degree {W['sh']}, "

@@ -110,7 +110,7 @@ def _views(device="cpu"):
     return rays, rgbs, alphas
 
 
-def train_steps(scene_mod, steps, batch, shard, sh=1, n_init=1200):
+def train_steps(scene_mod, steps, batch, shard, sh=1, n_init=1200, device="cpu"):
     """train.py:162-248's loop body on the reference's scene, `steps` iterations; data parallel when torch.distributed is
     initialised (the caller has enabled it).  Returns what the callers compare."""
     from types import SimpleNamespace
@@ -125,13 +125,13 @@ def train_steps(scene_mod, steps, batch, shard, sh=1, n_init=1200):
     margs = SimpleNamespace(sh_degree=sh, init_points=n_init, final_points=4 * n_init, activation_scale=1.0)
     oargs = SimpleNamespace(points_lr_init=2e-4, points_lr_final=5e-6, density_lr_init=1e-1, density_lr_final=1e-2,
                             attributes_lr_init=5e-3, attributes_lr_final=5e-4, sh_factor=0.1, freeze_points=18_000)
-    model = scene_mod.RadFoamScene(margs, device=torch.device("cpu"))
+    model = scene_mod.RadFoamScene(margs, device=torch.device(device))
     with torch.no_grad():
         model.att_dc.copy_(0.5 * torch.randn_like(model.att_dc))
         model.att_sh.copy_(0.2 * torch.randn_like(model.att_sh))
         model.density.copy_(-0.25 + 0.1 * torch.randn_like(model.density))
     model.declare_optimizer(oargs, warmup=100, max_iterations=1000)
-    rays, rgbs, alphas = _views()
+    rays, rgbs, alphas = (t.to(device) for t in _views())
     flat = lambda t: t.reshape(-1, t.shape[-1])
     # data_loader/__init__.py:113-127, unmodified call sites: after enable_data_parallel(shard_batches=True) these
     # shuffled fetchers serve the rank's share
@@ -145,7 +145,7 @@ def train_steps(scene_mod, steps, batch, shard, sh=1, n_init=1200):
     for i in range(steps):
         ray_batch, rgb_batch, alpha_batch = fr.next(), fc.next(), fa.next()
         assert ray_batch.shape == (local, 6)
-        q_full = torch.rand(batch, 2, generator=qgen).sort(dim=-1, descending=True).values      # train.py:176-180
+        q_full = torch.rand(batch, 2, generator=qgen).sort(dim=-1, descending=True).values.to(device)      # train.py:176-180
         q = q_full[rank * local:(rank + 1) * local] if local != batch else q_full
         rgba, depth, _, nint, _ = model(ray_batch, depth_quantiles=q)
         if first_outputs is None:
@@ -407,3 +407,91 @@ def test_coherent_shards_partition_a_batch_by_camera_and_direction():
     assert (which[o][1:] >= which[o][:-1]).all()
     with pytest.raises(RuntimeError, match="multiple of the world size"):
         rdist.coherent_shard(rays[:4095], 0, 8)
+
+
+def _gpu_worker(rank, world, port, shard, out_dir):
+    """Two ranks on ONE GPU (gloo moves CUDA tensors; RCCL refuses two ranks per device): the real thing on every rank --
+    HIP tracer, GPU triangulation, device-resident fetchers, the exchange kernels."""
+    sys.path.insert(0, ROOT)
+    import radfoam
+    from radfoam_amd import dist as rdist
+    from radfoam_amd.pipeline import Pipeline
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        scene_mod = _reference_scene()
+        rdist.enable_data_parallel(shard_batches=(shard == "caller"), shard=shard)
+        if shard == "rows":     # flat batches cut in the coherent order (rf_build_ray_order over the whole batch) already here
+            keep_init = rdist.DataParallelPipeline.__init__
+
+            def small_batches_too(self, *a, **k):
+                keep_init(self, *a, **k)
+                self.coherent_min_rays = 1024
+
+            rdist.DataParallelPipeline.__init__ = small_batches_too
+        res = train_steps(scene_mod, steps=3, batch=4096, shard=shard, sh=2, n_init=6000, device="cuda")
+        if shard == "rows":
+            assert res["model"].pipeline._cut is not None
+        pipe = res["model"].pipeline
+        assert isinstance(pipe, rdist.DataParallelPipeline) and isinstance(pipe.inner, Pipeline)
+        assert pipe.last_exchange["world"] == world and pipe.last_exchange["exchange"] == "dense"
+        rays = res["views"][0][0]
+        model = res["model"]
+        with pipe.replicated_inputs():          # a whole view on every rank: rows traced per rank, sparse row exchange
+            rgba, _, contrib, nint, _ = model(rays, return_contribution=True)
+            model.optimizer.zero_grad(set_to_none=True)
+            rgba.sum().backward()
+            assert pipe.last_exchange["exchange"] in ("sparse", "dense")
+            rdist.assert_replicas_agree({"rgba": rgba.detach(), "contribution": contrib.detach(),
+                                         "points_grad": model.primal_points.grad})
+        torch.save({"params": {k: v.cpu() for k, v in res["params"].items()}, "losses": res["losses"],
+                    "rgba": rgba.detach().cpu()}, os.path.join(out_dir, f"gpu{world}_{rank}.pt"))
+    finally:
+        rdist.disable_data_parallel()
+        dist.destroy_process_group()
+
+
+def _gpu_single(out_dir):
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    scene_mod = _reference_scene()
+    res = train_steps(scene_mod, steps=3, batch=4096, shard="caller", sh=2, n_init=6000, device="cuda")
+    model = res["model"]
+    rgba = model(res["views"][0][0])[0]
+    torch.save({"params": {k: v.cpu() for k, v in res["params"].items()}, "losses": res["losses"], "rgba": rgba.detach().cpu()},
+               os.path.join(out_dir, "gpu1_0.pt"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", ["caller", "rows"])
+def test_data_parallel_training_step_two_ranks_on_the_gpu(shard, tmp_path):
+    """The data-parallel step with NOTHING replaced: two processes on cuda:0 under gloo, each with the reference's scene on
+    the HIP tracer, the GPU triangulation (every rank rebuilds for itself: the replica check after the rebuild is a test of
+    its determinism across processes), device-resident fetchers and the pitched exchange kernels -- against one process on
+    the whole batches.  Same parameters to summation order (atomics), same bits on both ranks."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, shard, str(tmp_path))) for r in range(2)]
+    procs.append(ctx.Process(target=_gpu_single, args=(str(tmp_path),)))
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(timeout=600)
+    for pr in procs:
+        if pr.is_alive():
+            pr.kill()
+            pytest.fail("worker hung")
+        assert pr.exitcode == 0
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f"gpu2_{r}.pt")) for r in range(2))
+    one = torch.load(os.path.join(str(tmp_path), "gpu1_0.pt"))
+    for k, v in r0["params"].items():
+        assert torch.equal(v, r1["params"][k]), k
+        a, b = v.double(), one["params"][k].double()
+        assert float((a - b).norm() / b.norm()) < 1e-5, k
+    assert torch.equal(r0["rgba"], r1["rgba"])
+    torch.testing.assert_close(r0["rgba"], one["rgba"], rtol=1e-3, atol=1e-4)
+    if shard == "rows":
+        np.testing.assert_allclose(r0["losses"], one["losses"], rtol=1e-4)
+    else:
+        np.testing.assert_allclose(0.5 * (np.array(r0["losses"]) + np.array(r1["losses"])), one["losses"], rtol=1e-4)
