@@ -116,7 +116,12 @@ __device__ __forceinline__ int gather_seeds(const float *__restrict__ pts, uint3
             const uint32_t j = seed_adj[e];
             if (j < n && j != i) seeds[ns++] = j;
         }
-        if (ns >= 3) return ns;
+        if (ns >= 3) {
+#if RF_STAR_SORT_SEEDS
+            star::sort_seeds<V>(pts, pts + 3 * (size_t)i, seeds, ns);
+#endif
+            return ns;
+        }
         ns = 0;
     }
     // the nearest points of the block, by repeated selection of the next (distance, index) pair

@@ -42,6 +42,9 @@
 #ifndef RF_STAR_TRACE_QUERY   // instrumentation hook of the host harness: (tree nodes of the query, found a point)
 #define RF_STAR_TRACE_QUERY(nodes, found) ((void)0)
 #endif
+#ifndef RF_STAR_TRACE_SWEEP   // ... (how a star's sweep ended: 0 done, 3 out of budget; points offered; rounds; tree nodes)
+#define RF_STAR_TRACE_SWEEP(how, candidates, rounds, nodes) ((void)0)
+#endif
 
 namespace rf {
 namespace star {
@@ -536,23 +539,81 @@ RF_STAR_FN bool star_init(S &s, uint32_t ga, const float *pa, uint32_t gb, const
     return true;
 }
 
-// Bowyer-Watson on the link, in two steps so that a block of threads can share the first one.
-// star_mark: flag the triangles q conflicts with; returns how many.
+// What conflict() decides from the cached sphere alone, without a branch: +1 q conflicts with triangle t, -1 it does
+// not, 0 the float filter cannot tell (exact_conflict then).  qx, qy, qz = q - p_i.
 template <typename S>
-RF_STAR_FN int star_mark(S &s, const float *q) {
+RF_STAR_FN int filter_conflict(const S &s, int t, float qx, float qy, float qz) {
+    const uint8_t f = s.t[t].f;
+    const float sx = s.t[t].sx, sy = s.t[t].sy, sz = s.t[t].sz, sr = s.t[t].sr;
+    const float tx = sx * qx, ty = sy * qy, tz = sz * qz;
+    const float dg = tx + ty + tz;
+    const float ug = 4e-6f * (fabsf(tx) + fabsf(ty) + fabsf(tz)) + 1e-37f;
+    const float dx = qx - sx, dy = qy - sy, dz = qz - sz;
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    const float ub = 4e-6f * (d2 + sr) + 1e-37f;
+    const bool ghost = (f & kGhost) != 0;
+    const bool in = ghost ? dg > ug : d2 < sr - ub;
+    const bool out = ghost ? dg < -ug : d2 > sr + ub;
+    return (f & kSlow) ? 0 : (in ? 1 : (out ? -1 : 0));
+}
+
+// ... and what it decides when the filter cannot: the determinants (fp64 with an error bound, then exact)
+template <typename S>
+RF_STAR_FN bool exact_conflict(const S &s, int t, const float *q) {
+    if (s.t[t].f & kGhost) {
+        int a, b;
+        ghost_edge(s, t, a, b);
+        float pa[3], pb[3];
+        vertex_xyz(s, a, pa);
+        vertex_xyz(s, b, pb);
+        return orient_sign(s.p, pa, pb, q) > 0;
+    }
+    float pa[3], pb[3], pc[3];
+    vertex_xyz(s, s.t[t].a, pa);
+    vertex_xyz(s, s.t[t].b, pb);
+    vertex_xyz(s, s.t[t].c, pc);
+    return insphere_sign(s.p, pa, pb, pc, q) < 0;
+}
+
+// Bowyer-Watson on the link, in two steps so that a block of threads can share the first one.
+// star_mark: flag the triangles q conflicts with; returns how many, and lists the first `cap` of them (ascending) in
+// `hole`.  The kernels' stars live in scratch memory, where a load is a round trip to L2 or beyond: the first loop
+// classifies 64 triangles at a time by the float filter with neither a store nor a branch in it, so that the loads of
+// different triangles are in flight together (a loop that flags as it goes waits for every triangle in turn); the few
+// the filter cannot decide and the flags follow.
+template <typename S>
+RF_STAR_FN int star_mark(S &s, const float *q, uint32_t *hole, int cap) {
+    const float qx = q[0] - s.p[0], qy = q[1] - s.p[1], qz = q[2] - s.p[2];
     int marked = 0;
-    for (int t = 0; t < s.nt; ++t)
-        if (conflict(s, t, q)) {
-            s.t[t].f |= kMarked;
+    for (int base = 0; base < s.nt; base += 64) {
+        const int count = s.nt - base < 64 ? s.nt - base : 64;
+        unsigned long long in = 0ull, unsure = 0ull;
+        for (int k = 0; k < count; ++k) {
+            const int c = filter_conflict(s, base + k, qx, qy, qz);
+            in |= (unsigned long long)(c > 0) << k;
+            unsure |= (unsigned long long)(c == 0) << k;
+        }
+        while (unsure) {
+            const int k = __builtin_ctzll(unsure);
+            unsure &= unsure - 1ull;
+            if (exact_conflict(s, base + k, q)) in |= 1ull << k;
+        }
+        while (in) {
+            const int k = __builtin_ctzll(in);
+            in &= in - 1ull;
+            s.t[base + k].f |= kMarked;
+            if (marked < cap) hole[marked] = (uint32_t)(base + k);
             ++marked;
         }
+    }
     return marked;
 }
 
 // star_apply: the flagged triangles (`marked` of them; `hole` = their indices if the caller collected them, else
-// null) come out and the hole is fanned to q.  Returns `marked`, or -1 on failure.
+// null; `ascending`: the list is in ascending order) come out and the hole is fanned to q.  Returns `marked`, or -1 on
+// failure.
 template <typename S>
-RF_STAR_FN int star_apply(S &s, uint32_t gq, const float *q, int marked, const uint32_t *hole) {
+RF_STAR_FN int star_apply(S &s, uint32_t gq, const float *q, int marked, const uint32_t *hole, bool ascending = false) {
     const int nt0 = s.nt;
     int slot = -1;
     for (int k = 1; k < S::kV; ++k)
@@ -601,15 +662,26 @@ RF_STAR_FN int star_apply(S &s, uint32_t gq, const float *q, int marked, const u
     for (int t = nt0; t < nt; ++t) set_sphere(s, t);
     // drop the hole: move the last live triangle into every marked slot
     int vanished = 0;   // link vertices that were interior to the hole
-    int t = 0;
-    while (t < nt) {
-        if (!(s.t[t].f & kMarked)) {
-            ++t;
-            continue;
+    if (hole && ascending) {
+        // from the highest marked slot down: whatever lies above it is live by then, so the last triangle can go straight
+        // into it -- `marked` steps instead of a pass over all the triangles
+        for (int o = marked - 1; o >= 0; --o) {
+            const int t = (int)hole[o];
+            vanished += (--s.v[s.t[t].a].use == 0) + (--s.v[s.t[t].b].use == 0) + (--s.v[s.t[t].c].use == 0);
+            --nt;
+            if (t != nt) s.t[t] = s.t[nt];
         }
-        vanished += (--s.v[s.t[t].a].use == 0) + (--s.v[s.t[t].b].use == 0) + (--s.v[s.t[t].c].use == 0);
-        --nt;
-        if (t != nt) s.t[t] = s.t[nt];
+    } else {
+        int t = 0;
+        while (t < nt) {
+            if (!(s.t[t].f & kMarked)) {
+                ++t;
+                continue;
+            }
+            vanished += (--s.v[s.t[t].a].use == 0) + (--s.v[s.t[t].b].use == 0) + (--s.v[s.t[t].c].use == 0);
+            --nt;
+            if (t != nt) s.t[t] = s.t[nt];
+        }
     }
     s.nt = nt;
     // a hole that is a disc of m triangles around k interior vertices has m + 2 - 2k boundary edges
@@ -623,16 +695,12 @@ RF_STAR_FN int star_apply(S &s, uint32_t gq, const float *q, int marked, const u
 // Returns the number of triangles removed (0: q is not a neighbour), -1 on failure.
 template <typename S>
 RF_STAR_FN int star_insert(S &s, uint32_t gq, const float *q) {
-    const int marked = star_mark(s, q);
+    // the hole as a list when it is small (nearly always: a handful of triangles), the flags otherwise
+    constexpr int kList = S::kHole > 0 ? S::kHole : 24;
+    uint32_t hole[kList];
+    const int marked = star_mark(s, q, hole, kList);
     if (marked == 0) return 0;
-    if (S::kHole > 0 && marked <= S::kHole) {   // large instances: the hole is a handful of thousands of triangles
-        uint32_t hole[S::kHole > 0 ? S::kHole : 1];
-        int n = 0;
-        for (int t = 0; t < s.nt && n < marked; ++t)
-            if (s.t[t].f & kMarked) hole[n++] = (uint32_t)t;
-        return star_apply(s, gq, q, marked, hole);
-    }
-    return star_apply(s, gq, q, marked, nullptr);
+    return star_apply(s, gq, q, marked, marked <= kList ? hole : nullptr, true);
 }
 
 RF_STAR_FN float box_dist2(const float *nd, float x, float y, float z) {
@@ -919,6 +987,30 @@ RF_STAR_FN int star_knn_up(const Tree &tr, const float *pts, uint32_t self, uint
     return n;
 }
 
+// Seeds nearest first (insertion sort; CAP >= nseeds).  A previous neighbour list comes in ascending index order, i.e.
+// sweeping across the star from one side of the kd-order to the other: the link stays lopsided until the last seeds
+// arrive and every insertion re-triangulates a large hole.  Nearest first, each seed changes a few triangles only.
+#ifndef RF_STAR_SORT_SEEDS
+#define RF_STAR_SORT_SEEDS 1
+#endif
+template <int CAP>
+RF_STAR_FN void sort_seeds(const float *pts, const float *p, uint32_t *seeds, int nseeds) {
+    float d2[CAP];
+    for (int k = 0; k < nseeds; ++k) {
+        const uint32_t g = seeds[k];
+        const float dx = pts[3 * (size_t)g] - p[0], dy = pts[3 * (size_t)g + 1] - p[1], dz = pts[3 * (size_t)g + 2] - p[2];
+        const float d = dx * dx + dy * dy + dz * dz;
+        int pos = k;
+        while (pos > 0 && d2[pos - 1] > d) {
+            d2[pos] = d2[pos - 1];
+            seeds[pos] = seeds[pos - 1];
+            --pos;
+        }
+        d2[pos] = d;
+        seeds[pos] = g;
+    }
+}
+
 // Starting tetrahedron: the first seed triple that is not coplanar with p_i.  Sets kDegenerate if there is none.
 template <typename S>
 RF_STAR_FN void star_first_tet(S &s, const float *pts, const uint32_t *seeds, int nseeds, int *used) {
@@ -956,12 +1048,237 @@ RF_STAR_FN void star_seed(S &s, const float *pts, const uint32_t *seeds, int nse
     }
 }
 
+// ---- the sweep: one range query certifies the triangles of a star whose balls it covers -----------------------------
+// A circumball of the star passes through p_i, so it lies inside the ball of radius 2 r around p_i (r = its own radius).
+// And the region the star's balls cover only shrinks: the triangle (u, v, q) an insertion fans from a boundary edge
+// (u, v) of its hole has its ball inside ball(T1) u ball(T2), T1 the removed and T2 the kept triangle on that edge (the
+// three spheres share the circle through p_i, u, v; q lies inside T1's and not inside T2's; half-spaces of ghosts are
+// the limit case) -- which is also why a point that was offered to the link and did not conflict never conflicts later.
+// So ONE walk of the tree that offers every point within R of p_i to the link certifies, when it is done, every
+// triangle with 2 r <= R: a point inside such a ball lies within R, was offered, and conflicts with nothing that is
+// left.  That replaces a tree walk per triangle (27 for an average star, plus one per insertion) by one walk that meets
+// ~45 points, 16 of them the link's own vertices (scripts/model_star_churn.py has the numbers for a random foam).
+// R is 2 max r, except that a ball more than kSweepSpread times the star's smallest does not count: ghosts (the convex
+// hull), numerically flat triangles and the huge balls of the cloud's rim -- regions that reach far outside the cloud,
+// where a ball around p_i would cover half of it -- keep their own queries (the per-triangle loop of star_build).
+// The walk is taken in rounds: it pauses when its list is full, the list is offered to the link -- nearest subtrees
+// first, so the star is close to final after the first round --, R shrinks to what the balls need now, and the walk
+// goes on from where it stopped (whatever it passed was within the larger R).  Rounds keep the wave together: all lanes
+// walk, then all lanes insert.  RF_STAR_SWEEP=0 compiles the sweep out (A/B).
+#ifndef RF_STAR_SWEEP
+#define RF_STAR_SWEEP 1
+#endif
+#ifndef RF_STAR_SWEEP_CAP
+#define RF_STAR_SWEEP_CAP 64
+#endif
+#ifndef RF_STAR_SWEEP_SPREAD
+#define RF_STAR_SWEEP_SPREAD 25.0f   // (largest / smallest radius)^2 a star's balls may span and still all be swept
+#endif
+#ifndef RF_STAR_SWEEP_ON          // run-time switch of the host harness (tests compare both ways); a constant in the kernels
+#define RF_STAR_SWEEP_ON 1
+#endif
+constexpr int kSweepCap = RF_STAR_SWEEP_CAP;
+constexpr float kSweepSpread = RF_STAR_SWEEP_SPREAD;
+
+RF_STAR_FN uint32_t vertex_hash(uint32_t g) { return (g * 0x9E3779B1u) >> 26; }
+
+// squared radius of the sweep the star asks for now: (2 r)^2 of its largest ball that counts, with room for the
+// roundings of the cached radius, of the boxes' and of the points' distances; 0: no finite triangle
+template <typename S>
+RF_STAR_FN float sweep_reach(const S &s) {
+    float lo = 3.4e38f, hi = 0.0f;
+    for (int t = 0; t < s.nt; ++t) {
+        const float r = s.t[t].sr;   // ghosts: -1
+        if (r >= 0.0f) {
+            lo = fminf(lo, r);
+            hi = fmaxf(hi, r);
+        }
+    }
+    if (!(lo < 3.0e38f)) return 0.0f;
+    return 4.0f * fminf(hi, kSweepSpread * lo) * 1.0001f + 1e-37f;
+}
+
+// where a sweep's walk stands: the subtree it is in (d0, k0), the position inside it, the ancestors' siblings still to
+// visit (a bit per level), the tree nodes spent so far
+struct SweepWalk {
+    uint32_t d0, k0, ld, vidx, flip, reach, spent;
+    bool done;
+};
+
+// Start: p_i's bucket, then the sibling subtree of every ancestor that a ball of squared radius r2 reaches (the walk of
+// star_knn_up / search_subtree; independent loads: the addresses follow from s.self alone).
+template <typename S>
+RF_STAR_FN void sweep_begin(const S &s, const Tree &tr, float r2, SweepWalk &w, uint32_t &visited) {
+    const uint32_t leaf_depth = tr.depth - kLeafBits;
+    w.reach = 0;
+    for (uint32_t d = leaf_depth; d >= 1u; --d) {
+        const uint32_t sib = (s.self >> (tr.depth - d)) ^ 1u;
+        if ((sib << (tr.depth - d)) >= tr.n) continue;
+        if (box_dist2(tree_node(tr, d, sib), s.p[0], s.p[1], s.p[2]) <= r2) w.reach |= 1u << d;
+    }
+    visited += leaf_depth;
+    w.spent = leaf_depth;
+    w.d0 = leaf_depth;
+    w.k0 = s.self >> kLeafBits;
+    w.ld = w.vidx = w.flip = 0;
+    w.done = false;
+}
+
+// The next points within sqrt(r2) of p_i (the link's own vertices among them) until the walk is done or `out` has no
+// room for another bucket.  The leaf does nothing but measure and store: whatever a lane does rarely the wave does in
+// nearly every trip, so telling the link's vertices from new points is left to the caller's (convergent) loop over the
+// list.  Returns how many were written, or -1 when the walk has taken more than `budget` tree nodes.
+template <typename S>
+RF_STAR_FN int sweep_collect(S &s, const Tree &tr, const float *pts, float r2, SweepWalk &w, uint32_t *out, int cap,
+                             uint32_t budget, uint32_t &visited) {
+    const float px = s.p[0], py = s.p[1], pz = s.p[2];
+    const uint32_t leaf_depth = tr.depth - kLeafBits;
+    int count = 0;
+    bool duplicate = false;
+    while (!w.done && count + (1 << kLeafBits) <= cap) {
+        const uint32_t depth = w.d0 + w.ld;
+        const uint32_t idx = (w.k0 << w.ld) | (w.vidx ^ w.flip);
+        const uint32_t first = idx << (tr.depth - depth);
+        bool descend = false;
+        if (first < tr.n) {
+            const float *nd = tree_node(tr, depth, idx);
+            ++visited;
+            if (++w.spent > budget) return -1;
+            if (box_dist2(nd, px, py, pz) <= r2) {
+                if (depth < leaf_depth) {
+                    descend = true;
+                } else {
+                    const uint32_t end = first + (1u << kLeafBits) < tr.n ? first + (1u << kLeafBits) : tr.n;
+                    for (uint32_t k = first; k < end; ++k) {
+                        const float dx = pts[3 * (size_t)k] - px, dy = pts[3 * (size_t)k + 1] - py;
+                        const float dz = pts[3 * (size_t)k + 2] - pz;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        if (k == s.self || !(d2 <= r2)) continue;
+                        duplicate |= d2 == 0.0f;   // (or an underflow: looked at again below)
+                        out[count++] = k;
+                    }
+                }
+            }
+        }
+        if (descend) {
+            const uint32_t dim = depth % 3;
+            const float *left = tree_node(tr, depth + 1, 2 * idx);
+            const float pd = dim == 0 ? px : (dim == 1 ? py : pz);
+            const uint32_t right_first = pd > left[3 + dim] ? 1u : 0u;
+            ++w.ld;
+            w.vidx <<= 1;
+            w.flip = (w.flip << 1) | right_first;
+            continue;
+        }
+        ++w.vidx;
+        uint32_t up = (uint32_t)__builtin_ctz(w.vidx);
+        up = up < w.ld ? up : w.ld;
+        w.ld -= up;
+        w.vidx >>= up;
+        w.flip >>= up;
+        if (w.ld == 0) {
+            if (w.reach == 0u) {
+                w.done = true;
+            } else {
+                w.d0 = 31u - (uint32_t)__builtin_clz(w.reach);
+                w.reach &= ~(1u << w.d0);
+                w.k0 = (s.self >> (tr.depth - w.d0)) ^ 1u;
+                w.vidx = w.flip = 0;
+            }
+        }
+    }
+    if (duplicate)
+        for (int c = 0; c < count; ++c) {
+            const float *q = pts + 3 * (size_t)out[c];
+            if (q[0] == px && q[1] == py && q[2] == pz) s.status = kDuplicate;
+        }
+    return count;
+}
+
+// is the ball of triangle t inside a swept reach of squared radius r2?
+template <typename S>
+RF_STAR_FN bool swept_ball(const S &s, int t, float r2) {
+    const float r = s.t[t].sr;
+    return r >= 0.0f && 4.0f * r * 1.0001f + 1e-37f <= r2;
+}
+
+// Offers every point within reach of the star's (ordinary) balls to the link and certifies the triangles whose balls
+// that covers.  Returns the squared radius that was swept (0: nothing); triangles the star gets LATER are final too if
+// their ball lies inside it.  The star may fail on the way (s.status).
+template <typename S>
+RF_STAR_FN float star_sweep(S &s, const Tree &tr, const float *pts, uint32_t budget, uint32_t &visited,
+                            uint32_t &inserted) {
+    float r2 = sweep_reach(s);
+    if (!(r2 > 0.0f) || tr.depth <= (uint32_t)kLeafBits) return 0.0f;
+    SweepWalk w;
+    sweep_begin(s, tr, r2, w, visited);
+    uint32_t cand[kSweepCap];
+    int offered = 0, rounds = 0;
+    while (!w.done) {
+        ++rounds;
+        const int n = sweep_collect(s, tr, pts, r2, w, cand, kSweepCap, budget, visited);
+        if (s.status != kOk) return 0.0f;
+        if (n < 0) {   // out of budget: what was inserted stands, nothing is certified here
+            RF_STAR_TRACE_SWEEP(3, offered, rounds, w.spent);
+            return 0.0f;
+        }
+#if defined(RF_STAR_EXPERIMENT_STAGE) && RF_STAR_EXPERIMENT_STAGE == 2   // timing only: seeds + the walk, candidates dropped
+        offered += n;
+        continue;
+#endif
+        // the link's vertices are in the list too: a 64-bit filter over a hash of the id, the slots only on a filter hit
+        // (a point this loop inserts is not a candidate again, so the filter need not follow the link within a round)
+        unsigned long long filter = 0ull;
+        int top = 1;
+        for (int k = 1; k < S::kV; ++k)
+            if (s.v[k].use) {
+                filter |= 1ull << vertex_hash(s.v[k].g);
+                top = k + 1;
+            }
+        for (int c = 0; c < n; ++c) {
+            const uint32_t k = cand[c];
+            if ((filter >> vertex_hash(k)) & 1ull) {
+                bool vertex = false;
+                for (int v = 1; v < top && !vertex; ++v) vertex = s.v[v].use != 0 && s.v[v].g == k;
+                if (vertex) continue;
+            }
+            const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
+            const int r = star_insert(s, k, q);
+            if (r < 0) return 0.0f;   // overflow / broken: s.status says which
+            inserted += r > 0;
+        }
+        offered += n;
+        // the balls the star has now need less: the rest of the walk is shorter (never longer: what the walk passed
+        // was measured against the reach of that time)
+        if (!w.done) r2 = fminf(r2, sweep_reach(s));
+    }
+    RF_STAR_TRACE_SWEEP(0, offered, rounds, w.spent);
+#if defined(RF_STAR_EXPERIMENT_STAGE) && RF_STAR_EXPERIMENT_STAGE == 2
+    for (int t = 0; t < s.nt; ++t) s.t[t].f |= kCertified;
+    return r2;
+#endif
+    // every point within sqrt(r2) of p_i has been offered: a ball inside that reach is empty
+    for (int t = 0; t < s.nt; ++t)
+        if (swept_ball(s, t, r2)) s.t[t].f |= kCertified;
+    return r2;
+}
+
 // Build the star from `nseeds` candidate points, then certify every triangle.
 template <typename S>
 RF_STAR_FN void star_build(S &s, const Tree &tr, const float *pts, const HullSet &hull,
                            const uint32_t *seeds, int nseeds, uint32_t &visited, uint32_t &inserted) {
     star_seed(s, pts, seeds, nseeds, inserted);
     if (s.status != kOk) return;
+#if defined(RF_STAR_EXPERIMENT_STAGE) && RF_STAR_EXPERIMENT_STAGE == 1   // timing only: seeds, nothing certified
+    return;
+#endif
+#if RF_STAR_SWEEP
+    float swept = 0.0f;
+    if (RF_STAR_SWEEP_ON) {
+        swept = star_sweep(s, tr, pts, hull.budget, visited, inserted);
+        if (s.status != kOk) return;
+    }
+#endif
     for (;;) {
         int t = -1;
         for (int k = 0; k < s.nt; ++k)
@@ -970,6 +1287,13 @@ RF_STAR_FN void star_build(S &s, const Tree &tr, const float *pts, const HullSet
                 break;
             }
         if (t < 0) break;
+#if RF_STAR_SWEEP
+        // a triangle that came with an insertion after the sweep: final if its ball lies inside what was swept
+        if (swept > 0.0f && swept_ball(s, t, swept)) {
+            s.t[t].f |= kCertified;
+            continue;
+        }
+#endif
         float q[3];
         const uint32_t before = visited;
         const uint32_t j = star_search(s, tr, pts, t, hull, q, visited);

@@ -16,6 +16,22 @@ static thread_local std::vector<std::pair<uint32_t, int>> *g_trace = nullptr;
         if (g_trace) g_trace->emplace_back((uint32_t)(nodes), (int)(found)); \
     } while (0)
 
+// how the sweeps of the first-pass (small) stars ended: [0] done, [1] ghost, [2] flat triangle, [3] list / budget exceeded, [4] candidates of the done ones
+static long long g_sweep_stats[5];
+static thread_local uint32_t *g_sweep_rec = nullptr;   // star_host_sweep_trace: {how, offered, rounds, nodes} of the star being built
+#define RF_STAR_TRACE_SWEEP(how, candidates, rounds, nodes)                    \
+    do {                                                                       \
+        __atomic_fetch_add(&g_sweep_stats[how], 1, __ATOMIC_RELAXED);          \
+        if ((how) == 0) __atomic_fetch_add(&g_sweep_stats[4], (long long)(candidates), __ATOMIC_RELAXED); \
+        if (g_sweep_rec) {                                                     \
+            g_sweep_rec[0] = (uint32_t)(how);                                  \
+            g_sweep_rec[1] = (uint32_t)(candidates);                           \
+            g_sweep_rec[2] = (uint32_t)(rounds);                               \
+            g_sweep_rec[3] = (uint32_t)(nodes);                                \
+        }                                                                      \
+    } while (0)
+static int g_star_sweep = 1;   // star_host_set_sweep: the sweep of rf_star.hpp on / off (tests compare both ways)
+#define RF_STAR_SWEEP_ON g_star_sweep
 #define RF_STAR_FN static inline
 #define RF_STAR_NOINLINE static __attribute__((noinline))
 #define RF_STAR_NOUNROLL
@@ -40,6 +56,7 @@ static int one_star(const float *pts, uint32_t n, const Tree &tr, const HullSet 
     if (old_adj) {
         for (uint32_t e = old_off[i]; e < old_off[i + 1] && ns < V - 1; ++e) seeds[ns++] = old_adj[e];
         if (ns < 3) ns = 0;   // nothing usable in the previous list: the block's points, as gather_seeds does
+        else if (RF_STAR_SORT_SEEDS) sort_seeds<V>(pts, pts + 3 * (size_t)i, seeds, ns);
     }
     if (ns == 0) {
         uint32_t b0, bc;
@@ -220,7 +237,50 @@ int star_host_delaunay_owner(const float *pts, uint32_t n, const float *tree, ui
     return bad;
 }
 
+// Per star of [first, first + count), first-pass instance: out[k] = {how the sweep ended (0 done, 3 out of budget, 9 none),
+// points offered, rounds, tree nodes of the walk, queries of the per-triangle loop after it, their tree nodes (sum),
+// the largest of them, insertions}.  For the lockstep cost model of the sweep (scripts/model_star_sweep.py).
+int star_host_sweep_trace(const float *pts, uint32_t n, const float *tree, uint32_t depth, uint32_t knn, uint32_t budget,
+                          const uint32_t *old_adj, const uint32_t *old_off, uint32_t first, uint32_t count, uint32_t *out) {
+    Tree tr{tree, n, depth};
+    const HullSet pass{nullptr, 0, budget};
+    std::vector<uint32_t> row(4096), deg(n), vis(n), ins(n);
+    std::vector<uint8_t> ghost(n);
+    std::vector<uint32_t> ns_store(n, 0);
+    g_star_ns = ns_store.data();
+    for (uint32_t k = 0; k < count && first + k < n; ++k) {
+        std::vector<std::pair<uint32_t, int>> tr_q;
+        uint32_t *rec = out + 8 * (size_t)k;
+        rec[0] = 9;
+        rec[1] = rec[2] = rec[3] = 0;
+        g_trace = &tr_q;
+        g_sweep_rec = rec;
+        ins[first + k] = 0;
+        one_star<Star<64, 124>>(pts, n, tr, pass, first + k, knn, old_adj, old_off, row.data(), deg.data(), ghost.data(),
+                                vis.data(), ins.data());
+        g_trace = nullptr;
+        g_sweep_rec = nullptr;
+        rec[4] = (uint32_t)tr_q.size();
+        rec[5] = rec[6] = 0;
+        for (auto &q : tr_q) {
+            rec[5] += q.first;
+            rec[6] = q.first > rec[6] ? q.first : rec[6];
+        }
+        rec[7] = ins[first + k];
+    }
+    g_star_ns = nullptr;
+    return 0;
+}
+
 const uint32_t *star_host_times() { return g_star_ns; }
+
+void star_host_set_sweep(int on) { g_star_sweep = on; }
+void star_host_sweep_stats(long long *out, int reset) {
+    for (int k = 0; k < 5; ++k) {
+        out[k] = g_sweep_stats[k];
+        if (reset) g_sweep_stats[k] = 0;
+    }
+}
 
 // First-pass query traces of the stars [first, first + count): out[k * cap + q] = tree nodes of query q of star k
 // (bit 31: the query found a point), lengths[k] = number of queries.  For the lockstep cost model.

@@ -69,8 +69,11 @@ def aabb_tree(points: np.ndarray) -> np.ndarray:
     return tree
 
 
-def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250, ghost_budget: int = 512):
-    """(offsets, adjacency, info) through the host build of the star code."""
+def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250, ghost_budget: int = 512,
+             sweep: bool = True):
+    """(offsets, adjacency, info) through the host build of the star code; sweep=False: every triangle certified by a
+    query of its own (rf_star.hpp: star_sweep compiled in but switched off)."""
+    lib().star_host_set_sweep(1 if sweep else 0)
     pts = np.ascontiguousarray(points, dtype=np.float32)
     n = pts.shape[0]
     tree = aabb_tree(pts)
