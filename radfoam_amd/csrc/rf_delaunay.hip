@@ -221,9 +221,29 @@ struct CoopResult {
     bool duplicate;
 };
 
+// One wave answers one query: the tree is walked six levels at a time -- the 64 descendants of a node six levels down are
+// consecutive in memory: a box per lane, a ballot keeps what the region touches -- from a stack of {level, first node,
+// ballot} entries in LDS.  kCoopUnroll blocks of 64 boxes are requested per trip (the children of up to that many set
+// bits of the entry on top), so that their loads are in flight together: the expensive queries of this pass -- the
+// half-space-like balls of the rim, 10^5 boxes that all have to be looked at -- are chains of such trips, each a
+// round trip to L2 (one block per trip: 76 / 31 ms for the second pass of the 2 M-point foam from scratch /
+// incrementally; four: see profiles/README.md r06).
+#ifndef RF_COOP_UNROLL
+#define RF_COOP_UNROLL 4
+#endif
+constexpr int kCoopUnroll = RF_COOP_UNROLL;
+constexpr int kCoopStack = 40;   // entries: at most kCoopUnroll per level below an entry that is still open, 6 levels
+
+struct CoopStack {
+    unsigned long long mask[kCoopStack];
+    uint32_t base[kCoopStack];
+    uint32_t level[kCoopStack];
+};
+
 template <typename S>
 __device__ CoopResult coop_search(const S &s, const star::Tree &tr, const float *__restrict__ pts, int t,
-                                  const uint32_t *__restrict__ hull_ids, uint32_t hull_count, uint32_t &visited) {
+                                  const uint32_t *__restrict__ hull_ids, uint32_t hull_count, uint32_t &visited,
+                                  CoopStack *stack) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint8_t f = s.t[t].f;
     const bool ghost = (f & star::kGhost) != 0;
@@ -266,44 +286,99 @@ __device__ CoopResult coop_search(const S &s, const star::Tree &tr, const float 
     } else {
         const uint32_t leaf_depth = tr.depth - star::kLeafBits;
         const uint32_t d0 = leaf_depth % 6;
-        unsigned long long mask[6];
-        uint32_t base[6];
-        int level = 0;
-        base[0] = 0;
-        for (;;) {
-            const uint32_t depth = d0 + 6u * (uint32_t)level;
-            const uint32_t width = level == 0 ? (1u << d0) : 64u;
-            const uint32_t idx = base[level] + lane;
-            const uint32_t first = idx << (tr.depth - depth);
+        // does the region touch the box?
+        auto touches = [&](const float *nd) {
+            bool ok = star::box_dist2(nd, px, py, pz) < best;
+            if (ok && ball) ok = star::box_dist2(nd, cx, cy, cz) <= rp2;
+            if (ok && ghost && !(f & star::kSlow)) {
+                const float ax = nx > 0 ? nd[3] - px : nd[0] - px, ay = ny > 0 ? nd[4] - py : nd[1] - py;
+                const float az = nz > 0 ? nd[5] - pz : nd[2] - pz;
+                const float tx = nx * ax, ty = ny * ay, tz = nz * az;
+                ok = tx + ty + tz > -4e-6f * (fabsf(tx) + fabsf(ty) + fabsf(tz));
+            }
+            return ok;
+        };
+        // the points of a leaf bucket
+        auto bucket = [&](uint32_t first) {
+            const uint32_t end = first + (1u << star::kLeafBits) < tr.n ? first + (1u << star::kLeafBits) : tr.n;
+            for (uint32_t k = first; k < end; ++k) try_point(k);
+        };
+        volatile __attribute__((address_space(3))) CoopStack *st =
+            (volatile __attribute__((address_space(3))) CoopStack *)stack;
+        int sp = 0;
+        {   // level 0: all 2^d0 nodes of depth d0
+            const uint32_t width = 1u << d0;
+            const uint32_t first = lane << (tr.depth - d0);
             bool ok = lane < width && first < tr.n;
-            if (ok) {
-                const float *nd = star::tree_node(tr, depth, idx);
-                ok = star::box_dist2(nd, px, py, pz) < best;
-                if (ok && ball) ok = star::box_dist2(nd, cx, cy, cz) <= rp2;
-                if (ok && ghost && !(f & star::kSlow)) {
-                    const float ax = nx > 0 ? nd[3] - px : nd[0] - px, ay = ny > 0 ? nd[4] - py : nd[1] - py;
-                    const float az = nz > 0 ? nd[5] - pz : nd[2] - pz;
-                    const float tx = nx * ax, ty = ny * ay, tz = nz * az;
-                    ok = tx + ty + tz > -4e-6f * (fabsf(tx) + fabsf(ty) + fabsf(tz));
-                }
-            }
+            if (ok) ok = touches(star::tree_node(tr, d0, lane));
             visited += width;
-            if (depth == leaf_depth) {
-                if (ok) {
-                    const uint32_t end = first + (1u << star::kLeafBits) < tr.n ? first + (1u << star::kLeafBits) : tr.n;
-                    for (uint32_t k = first; k < end; ++k) try_point(k);
-                }
-                best = wave_min(my_d2);
-                mask[level] = 0;
+            if (d0 == leaf_depth) {
+                if (ok) bucket(first);
             } else {
-                mask[level] = __ballot(ok);
+                const unsigned long long m = __ballot(ok);
+                if (m) {
+                    if (lane == 0) {
+                        st->mask[0] = m;
+                        st->base[0] = 0u;
+                        st->level[0] = 0u;
+                    }
+                    sp = 1;
+                }
             }
-            while (mask[level] == 0 && level > 0) --level;
-            if (mask[level] == 0) break;
-            const uint32_t k = (uint32_t)__builtin_ctzll(mask[level]);
-            mask[level] &= mask[level] - 1;
-            base[level + 1] = (base[level] + k) << 6;
-            ++level;
+        }
+        while (sp > 0) {
+            unsigned long long m = st->mask[sp - 1];
+            const uint32_t pbase = st->base[sp - 1], plevel = st->level[sp - 1];
+            // the children of up to kCoopUnroll nodes of the entry on top: blocks of 64 boxes at the next level
+            uint32_t cbase[kCoopUnroll];
+            int blocks = 0;
+#pragma unroll
+            for (int u = 0; u < kCoopUnroll; ++u) {
+                cbase[u] = 0u;
+                if (m) {
+                    cbase[u] = (pbase + (uint32_t)__builtin_ctzll(m)) << 6;
+                    m &= m - 1ull;
+                    blocks = u + 1;
+                }
+            }
+            if (m == 0ull) --sp;
+            else if (lane == 0) st->mask[sp - 1] = m;
+            const uint32_t level = plevel + 1u, depth = d0 + 6u * level;
+            const bool leaves = depth == leaf_depth;
+            float box[kCoopUnroll][6];
+            bool ok[kCoopUnroll];
+#pragma unroll
+            for (int u = 0; u < kCoopUnroll; ++u) {   // the requests of all the blocks first
+                const uint32_t idx = cbase[u] + lane;
+                ok[u] = u < blocks && ((idx << (tr.depth - depth)) < tr.n);
+                if (ok[u]) {
+                    const float *nd = star::tree_node(tr, depth, idx);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) box[u][c] = nd[c];
+                }
+            }
+            visited += 64u * (uint32_t)blocks;
+            bool found = false;
+#pragma unroll
+            for (int u = 0; u < kCoopUnroll; ++u) {
+                if (u >= blocks) break;   // wave-uniform
+                if (ok[u]) ok[u] = touches(box[u]);
+                if (leaves) {
+                    if (ok[u]) bucket((cbase[u] + lane) << (tr.depth - depth));
+                    found = true;
+                } else {
+                    const unsigned long long cm = __ballot(ok[u]);
+                    if (cm) {
+                        if (lane == 0) {
+                            st->mask[sp] = cm;
+                            st->base[sp] = cbase[u];
+                            st->level[sp] = level;
+                        }
+                        ++sp;
+                    }
+                }
+            }
+            if (found) best = wave_min(my_d2);
         }
     }
     // the nearest candidate of the wave, the lower index on ties
@@ -335,6 +410,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
     __shared__ uint32_t seeds[kBigV];
     __shared__ int pick[kCoopWaves];
     __shared__ CoopResult found[kCoopWaves];
+    __shared__ CoopStack stacks[kCoopWaves];
     const uint32_t w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     if (w >= count) return;
     const uint32_t i = overflow_list[w];
@@ -369,7 +445,7 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
         if (pick[0] < 0) break;
         const int t = pick[wave];
         if (t >= 0) {
-            const CoopResult r = coop_search(s, tr, pts, t, hull_list, hull_count, visited);
+            const CoopResult r = coop_search(s, tr, pts, t, hull_list, hull_count, visited, &stacks[wave]);
             if ((tid & 63u) == 0) found[wave] = r;
         }
         __syncthreads();
@@ -449,6 +525,7 @@ __global__ __launch_bounds__(64 * kHugeWaves) void delaunay_star_huge_kernel(
     __shared__ int nhole;
     __shared__ int pick[kHugeWaves];
     __shared__ CoopResult found[kHugeWaves];
+    __shared__ CoopStack stacks[kHugeWaves];
     __shared__ int ok;
     const uint32_t b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     const uint32_t total = counters->huge;
@@ -497,7 +574,7 @@ __global__ __launch_bounds__(64 * kHugeWaves) void delaunay_star_huge_kernel(
         if (pick[0] < 0) break;
         const int t = pick[wave];
         if (t >= 0) {
-            const CoopResult r = coop_search(s, tr, pts, t, hull_list, hull_count, visited);
+            const CoopResult r = coop_search(s, tr, pts, t, hull_list, hull_count, visited, &stacks[wave]);
             if ((tid & 63u) == 0) found[wave] = r;
         }
         __syncthreads();

@@ -575,6 +575,23 @@ RF_STAR_FN bool exact_conflict(const S &s, int t, const float *q) {
     return insphere_sign(s.p, pa, pb, pc, q) < 0;
 }
 
+// lowest free vertex slot (never 0: the point at infinity), or -1.  The scan looks at 64 slots per trip with neither a
+// branch nor a store inside the trip, so that its loads are in flight together: a loop that leaves at the first hit waits
+// for every record in turn, and in the kernels a record is a round trip to L2 or beyond (the stars live in scratch
+// memory).  The same form of the search for the first uncertified triangle was measured and is no faster (the
+// certified ones come first, the loop leaves early): profiles/r06.
+template <typename S>
+RF_STAR_FN int free_slot(const S &s) {
+    for (int base = 0; base < S::kV; base += 64) {
+        const int count = S::kV - base < 64 ? S::kV - base : 64;
+        unsigned long long free_mask = 0ull;
+        for (int k = 0; k < count; ++k) free_mask |= (unsigned long long)(s.v[base + k].use == 0) << k;
+        if (base == 0) free_mask &= ~1ull;
+        if (free_mask) return base + __builtin_ctzll(free_mask);
+    }
+    return -1;
+}
+
 // Bowyer-Watson on the link, in two steps so that a block of threads can share the first one.
 // star_mark: flag the triangles q conflicts with; returns how many, and lists the first `cap` of them (ascending) in
 // `hole`.  The kernels' stars live in scratch memory, where a load is a round trip to L2 or beyond: the first loop
@@ -615,12 +632,7 @@ RF_STAR_FN int star_mark(S &s, const float *q, uint32_t *hole, int cap) {
 template <typename S>
 RF_STAR_FN int star_apply(S &s, uint32_t gq, const float *q, int marked, const uint32_t *hole, bool ascending = false) {
     const int nt0 = s.nt;
-    int slot = -1;
-    for (int k = 1; k < S::kV; ++k)
-        if (s.v[k].use == 0) {
-            slot = k;
-            break;
-        }
+    const int slot = free_slot(s);
     if (slot < 0) {
         s.status = kOverflow;
         return -1;
@@ -1066,7 +1078,7 @@ RF_STAR_FN void star_seed(S &s, const float *pts, const uint32_t *seeds, int nse
 // goes on from where it stopped (whatever it passed was within the larger R).  Rounds keep the wave together: all lanes
 // walk, then all lanes insert.  RF_STAR_SWEEP=0 compiles the sweep out (A/B).
 #ifndef RF_STAR_SWEEP
-#define RF_STAR_SWEEP 1
+#define RF_STAR_SWEEP 0   // measured out on the GPU (profiles/r06): 148-184 ms against 145 for 2 M points (see below)
 #endif
 #ifndef RF_STAR_SWEEP_CAP
 #define RF_STAR_SWEEP_CAP 64
@@ -1095,7 +1107,19 @@ RF_STAR_FN float sweep_reach(const S &s) {
         }
     }
     if (!(lo < 3.0e38f)) return 0.0f;
-    return 4.0f * fminf(hi, kSweepSpread * lo) * 1.0001f + 1e-37f;
+    float reach = 4.0f * fminf(hi, kSweepSpread * lo) * 1.0001f + 1e-37f;
+#if defined(RF_STAR_SWEEP_FAR)
+    // ... nor more than RF_STAR_SWEEP_FAR times the distance of the farthest link vertex (2 r >= that distance for every
+    // ball at the vertex): the walk of a star with one large ball stays as short as its neighbours' in the wave
+    float far2 = 0.0f;
+    for (int k = 1; k < S::kV; ++k) {
+        const float dx = s.v[k].x - s.p[0], dy = s.v[k].y - s.p[1], dz = s.v[k].z - s.p[2];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        far2 = s.v[k].use != 0 ? fmaxf(far2, d2) : far2;
+    }
+    reach = fminf(reach, (float)(RF_STAR_SWEEP_FAR) * (float)(RF_STAR_SWEEP_FAR) * far2);
+#endif
+    return reach;
 }
 
 // where a sweep's walk stands: the subtree it is in (d0, k0), the position inside it, the ancestors' siblings still to
@@ -1230,16 +1254,16 @@ RF_STAR_FN float star_sweep(S &s, const Tree &tr, const float *pts, uint32_t bud
         // (a point this loop inserts is not a candidate again, so the filter need not follow the link within a round)
         unsigned long long filter = 0ull;
         int top = 1;
-        for (int k = 1; k < S::kV; ++k)
-            if (s.v[k].use) {
-                filter |= 1ull << vertex_hash(s.v[k].g);
-                top = k + 1;
-            }
+        for (int k = 1; k < S::kV; ++k) {   // (no branch: see free_slot)
+            const bool used = s.v[k].use != 0;
+            filter |= (unsigned long long)used << vertex_hash(s.v[k].g);
+            top = used ? k + 1 : top;
+        }
         for (int c = 0; c < n; ++c) {
             const uint32_t k = cand[c];
             if ((filter >> vertex_hash(k)) & 1ull) {
                 bool vertex = false;
-                for (int v = 1; v < top && !vertex; ++v) vertex = s.v[v].use != 0 && s.v[v].g == k;
+                for (int v = 1; v < top; ++v) vertex |= (s.v[v].use != 0) & (s.v[v].g == k);
                 if (vertex) continue;
             }
             const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
