@@ -21,6 +21,7 @@
 //   csr_*                    degrees -> offsets (rocPRIM scan) -> adjacency, ascending per point like find_adjacency's
 //   symmetry_kernel          j in N(i) <=> i in N(j): exact predicates make independent stars agree; cospherical
 //                            input can break that, which is reported (the reference throws "ambiguous triangulation")
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -102,6 +103,11 @@ struct StarCounters {
     uint32_t adjacency;    // E
     uint32_t nodes_lo, nodes_hi;   // tree nodes visited (64-bit)
     uint32_t inserted;     // link insertions
+#ifdef RF_COOP_SECTIONS        // instrumentation: wave clocks (/1024) of the second pass's slowest block, by section
+    uint32_t sec_max[4];       // seed, queries, surgery, whole block
+    uint32_t sec_who;          // the star of the slowest block
+    uint32_t sec_rounds, sec_nt, sec_deg;
+#endif
 };
 
 template <int V, int T>
@@ -218,6 +224,7 @@ __device__ __forceinline__ float wave_min(float v) {
 struct CoopResult {
     uint32_t id;
     float q[3];
+    float d2;        // squared distance of q from the star's point (the waves that share a query compare by it)
     bool duplicate;
 };
 
@@ -243,7 +250,7 @@ struct CoopStack {
 template <typename S>
 __device__ CoopResult coop_search(const S &s, const star::Tree &tr, const float *__restrict__ pts, int t,
                                   const uint32_t *__restrict__ hull_ids, uint32_t hull_count, uint32_t &visited,
-                                  CoopStack *stack) {
+                                  CoopStack *stack, uint32_t part = 0u, uint32_t parts = 1u) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint8_t f = s.t[t].f;
     const bool ghost = (f & star::kGhost) != 0;
@@ -279,10 +286,13 @@ __device__ CoopResult coop_search(const S &s, const star::Tree &tr, const float 
         my_q[2] = q[2];
     };
 
+    // `parts` waves share this query: wave `part` takes every parts-th block of the hull candidates / every parts-th
+    // subtree below the first level of the walk (the top of the tree is looked at by all of them); the caller keeps
+    // the nearest of their answers
     if (ghost && hull_ids) {
-        for (uint32_t base = 0; base < hull_count; base += 64)
+        for (uint32_t base = 64u * part; base < hull_count; base += 64u * parts)
             if (base + lane < hull_count) try_point(hull_ids[base + lane]);
-        visited += hull_count;
+        visited += hull_count / parts;
     } else {
         const uint32_t leaf_depth = tr.depth - star::kLeafBits;
         const uint32_t d0 = leaf_depth % 6;
@@ -313,7 +323,7 @@ __device__ CoopResult coop_search(const S &s, const star::Tree &tr, const float 
             if (ok) ok = touches(star::tree_node(tr, d0, lane));
             visited += width;
             if (d0 == leaf_depth) {
-                if (ok) bucket(first);
+                if (ok && part == 0u) bucket(first);
             } else {
                 const unsigned long long m = __ballot(ok);
                 if (m) {
@@ -363,6 +373,8 @@ __device__ CoopResult coop_search(const S &s, const star::Tree &tr, const float 
             for (int u = 0; u < kCoopUnroll; ++u) {
                 if (u >= blocks) break;   // wave-uniform
                 if (ok[u]) ok[u] = touches(box[u]);
+                // the subtrees below the first level are dealt to the waves that share the query
+                if (plevel == 0u && parts > 1u) ok[u] = ok[u] && (lane % parts) == part;
                 if (leaves) {
                     if (ok[u]) bucket((cbase[u] + lane) << (tr.depth - depth));
                     found = true;
@@ -388,6 +400,7 @@ __device__ CoopResult coop_search(const S &s, const star::Tree &tr, const float 
     r.duplicate = __ballot(duplicate) != 0;
     r.id = star::kInfinity;
     r.q[0] = r.q[1] = r.q[2] = 0.0f;
+    r.d2 = d;
     if (holders) {
         const int src = (int)__builtin_ctzll(holders);
         r.id = __shfl(my_id, src, 64);
@@ -398,8 +411,11 @@ __device__ CoopResult coop_search(const S &s, const star::Tree &tr, const float 
     return r;
 }
 
-// kCoopWaves waves per second-pass star: that many of its queries run at the same time
-template <int kCoopWaves>
+// kCoopWaves waves per second-pass star, kCoopGroup of them on each query: kCoopWaves / kCoopGroup of the star's queries run
+// at the same time.  The launch lasts as long as its slowest star -- a rim star whose ~40 rounds each wait for a query of
+// 10^5-10^6 boxes answered by ONE wave (issue-bound: 76 % of that block's clocks, -DRF_COOP_SECTIONS=1) --, so the waves
+// that share a query shorten the launch although they do not shorten the work.
+template <int kCoopWaves, int kCoopGroup>
 __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
     const float *__restrict__ pts, uint32_t n, const float *__restrict__ tree, uint32_t depth,
     const uint32_t *__restrict__ seed_adj, const uint32_t *__restrict__ seed_off,
@@ -408,7 +424,8 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
     uint32_t *__restrict__ degree, uint32_t *__restrict__ huge_list, StarCounters *__restrict__ counters) {
     __shared__ BigStar s;
     __shared__ uint32_t seeds[kBigV];
-    __shared__ int pick[kCoopWaves];
+    constexpr int kQueries = kCoopWaves / kCoopGroup;
+    __shared__ int pick[kQueries];
     __shared__ CoopResult found[kCoopWaves];
     __shared__ CoopStack stacks[kCoopWaves];
     const uint32_t w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
@@ -416,6 +433,10 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
     const uint32_t i = overflow_list[w];
     const star::Tree tr{tree, n, depth};
     uint32_t visited = 0, inserted = 0;
+#ifdef RF_COOP_SECTIONS
+    unsigned long long c_seed = 0, c_query = 0, c_surgery = 0, c_rounds = 0;
+    const unsigned long long c_start = __builtin_readcyclecounter();
+#endif
     if (tid == 0) {
         star::star_reset(s, i, pts + 3 * (size_t)i);
         uint32_t block_first, block_count;
@@ -428,13 +449,19 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
                                             block_count, seeds, kBigV - 1);
         }
         star::star_seed(s, pts, seeds, ns, inserted);
+#ifdef RF_COOP_SECTIONS
+        c_seed = __builtin_readcyclecounter() - c_start;
+#endif
     }
     for (;;) {
+#ifdef RF_COOP_SECTIONS
+        const unsigned long long r0 = __builtin_readcyclecounter();
+#endif
         // a round: every wave takes one uncertified triangle; certification is a statement about the whole point
         // set, so it holds whatever the other waves' answers do to the link afterwards
         if (tid == 0) {
             int k = 0;
-            for (int v = 0; v < kCoopWaves; ++v) {
+            for (int v = 0; v < kQueries; ++v) {
                 pick[v] = -1;
                 if (s.status != star::kOk) continue;
                 while (k < s.nt && (s.t[k].f & star::kCertified)) ++k;
@@ -443,20 +470,43 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
         }
         __syncthreads();
         if (pick[0] < 0) break;
-        const int t = pick[wave];
+        const int t = pick[wave / kCoopGroup];
         if (t >= 0) {
-            const CoopResult r = coop_search(s, tr, pts, t, hull_list, hull_count, visited, &stacks[wave]);
+            const CoopResult r = coop_search(s, tr, pts, t, hull_list, hull_count, visited, &stacks[wave],
+                                             wave % kCoopGroup, (uint32_t)kCoopGroup);
             if ((tid & 63u) == 0) found[wave] = r;
         }
         __syncthreads();
+#ifdef RF_COOP_SECTIONS
+        const unsigned long long r1 = __builtin_readcyclecounter();
+        c_query += r1 - r0;
+        c_rounds++;
+#endif
         if (tid == 0) {
+            // the answer of a query: the nearest of its waves' (the lower index on ties), in the first wave's slot
+            for (int v = 0; v < kQueries; ++v) {
+                if (pick[v] < 0) continue;
+                CoopResult &a = found[v * kCoopGroup];
+                for (int g = 1; g < kCoopGroup; ++g) {
+                    const CoopResult &b = found[v * kCoopGroup + g];
+                    a.duplicate = a.duplicate || b.duplicate;
+                    if (b.id != star::kInfinity && (a.id == star::kInfinity || b.d2 < a.d2 || (b.d2 == a.d2 && b.id < a.id))) {
+                        a.id = b.id;
+                        a.d2 = b.d2;
+                        a.q[0] = b.q[0];
+                        a.q[1] = b.q[1];
+                        a.q[2] = b.q[2];
+                    }
+                }
+                if (v) found[v] = found[v * kCoopGroup];
+            }
             // certifications first (triangle indices are still those of the round), insertions after
-            for (int v = 0; v < kCoopWaves; ++v) {
+            for (int v = 0; v < kQueries; ++v) {
                 if (pick[v] < 0) continue;
                 if (found[v].duplicate) s.status = star::kDuplicate;
                 else if (found[v].id == star::kInfinity) s.t[pick[v]].f |= star::kCertified;
             }
-            for (int v = 0; v < kCoopWaves && s.status == star::kOk; ++v) {
+            for (int v = 0; v < kQueries && s.status == star::kOk; ++v) {
                 if (pick[v] < 0 || found[v].id == star::kInfinity) continue;
                 // 0 = the triangle this point conflicted with went with an earlier insertion of the round, and the
                 // point conflicts with nothing that replaced it
@@ -464,7 +514,25 @@ __global__ __launch_bounds__(64 * kCoopWaves) void delaunay_star_coop_kernel(
             }
         }
         __syncthreads();
+#ifdef RF_COOP_SECTIONS
+        c_surgery += __builtin_readcyclecounter() - r1;
+#endif
     }
+#ifdef RF_COOP_SECTIONS
+    if (tid == 0) {
+        const unsigned long long whole = __builtin_readcyclecounter() - c_start;
+        const uint32_t w1024 = (uint32_t)(whole >> 10);
+        if (atomicMax(&counters->sec_max[3], w1024) < w1024) {   // (racy on purpose: a diagnostic)
+            counters->sec_max[0] = (uint32_t)(c_seed >> 10);
+            counters->sec_max[1] = (uint32_t)(c_query >> 10);
+            counters->sec_max[2] = (uint32_t)(c_surgery >> 10);
+            counters->sec_who = i;
+            counters->sec_rounds = (uint32_t)c_rounds;
+            counters->sec_nt = (uint32_t)s.nt;
+            counters->sec_deg = (uint32_t)degree[i];
+        }
+    }
+#endif
     if ((tid & 63u) == 0) {
         const uint32_t old = atomicAdd(&counters->nodes_lo, visited);
         if (old + visited < old) atomicAdd(&counters->nodes_hi, 1u);
@@ -911,16 +979,25 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
         const bool use_list = host.hull <= 65536u;
         static const int coop_waves = [] {   // tuning only
             const char *e = getenv("RF_DELAUNAY_COOP_WAVES");
-            return e ? atoi(e) : 4;
+            return e ? atoi(e) : 8;
         }();
-#define RF_LAUNCH_COOP(W)                                                                                            \
-    hipLaunchKernelGGL(delaunay_star_coop_kernel<W>, dim3(host.overflow), dim3(64 * W), 0, s, points, num_points,    \
+#define RF_LAUNCH_COOP(W, G)                                                                                         \
+    hipLaunchKernelGGL((delaunay_star_coop_kernel<W, G>), dim3(host.overflow), dim3(64 * W), 0, s, points, num_points, \
                        aabb_tree, depth, seed_adjacency, seed_offsets, overflow,                                     \
                        use_list ? hull : (const uint32_t *)nullptr, host.hull, host.overflow, rows, big_rows, degree, \
                        huge_list, counters)
-        if (coop_waves >= 4) RF_LAUNCH_COOP(4);
-        else if (coop_waves >= 2) RF_LAUNCH_COOP(2);
-        else RF_LAUNCH_COOP(1);
+        static const int coop_group = [] {   // tuning only: waves per query
+            const char *e = getenv("RF_DELAUNAY_COOP_GROUP");
+            return e ? atoi(e) : 8;
+        }();
+        // (8 x 8: all the waves of a block on one query at a time -- measured 120 / 192 ms for the whole build of 2 M points,
+        // incrementally / from scratch, against 135 / 233 with four queries of one wave each: profiles/r06/t_coop_groups.log)
+        if (coop_waves >= 16) RF_LAUNCH_COOP(16, 16);
+        else if (coop_waves >= 8 && coop_group >= 8) RF_LAUNCH_COOP(8, 8);
+        else if (coop_waves >= 8) RF_LAUNCH_COOP(8, 4);
+        else if (coop_waves >= 4 && coop_group >= 4) RF_LAUNCH_COOP(4, 4);
+        else if (coop_waves >= 4) RF_LAUNCH_COOP(4, 1);
+        else RF_LAUNCH_COOP(1, 1);
 #undef RF_LAUNCH_COOP
         hipLaunchKernelGGL(mark_big_rows_kernel, dim3((host.overflow + 255u) / 256u), dim3(256), 0, s, overflow,
                            host.overflow, rows);
@@ -954,6 +1031,10 @@ int rf_delaunay_adjacency(const float *points, uint32_t num_points, const float 
     info[9] = host.failed[star::kBroken];
     info[10] = host.failed[star::kOverflow];
     info[11] = host.hull;
+#ifdef RF_COOP_SECTIONS
+    fprintf(stderr, "[coop sections] slowest block: star %u (first-pass link %u vertices, %u triangles at the end) whole %u seed %u queries %u surgery %u kcycles, %u rounds; hull candidates %u, second-pass stars %u\n",
+            host.sec_who, host.sec_deg, host.sec_nt, host.sec_max[3], host.sec_max[0], host.sec_max[1], host.sec_max[2], host.sec_rounds, host.hull, host.overflow);
+#endif
     return check_launch("rf_delaunay_adjacency");
 }
 

@@ -1,12 +1,11 @@
 # the batch of one gpurun call (rewritten per call; what each call ran is recorded in profiles/README.md)
-# this call (r06 r16): first pass at 4 waves per SIMD (RF_DELAUNAY_WAVES=4: 128 VGPRs) on the fast (bA) and the slow (base) build
+# this call (r06 t4): second pass with the waves of a block sharing queries (RF_DELAUNAY_COOP_WAVES x RF_DELAUNAY_COOP_GROUP), GPU tests of the triangulation
 R=$GRAFT_REPO_ROOT
 cd $R
-mkdir -p gpurun_out/r
-echo "-- r22 (kept: two-pass star_mark, hole list, sorted seeds, free_slot; the sweep compiled out; second pass with four blocks per trip)" >> gpurun_out/r/delaunay_stages.log
-for v in base bA; do
-  L=$R/radfoam_amd/libradfoam_hip_$v.so
-  [ "$v" = "base" ] && L=$R/radfoam_amd/libradfoam_hip.so
-  RADFOAM_HIP_LIB=$L timeout 600 python scripts/gpu_delaunay_stages.py 2>&1 | grep -v amdgpu.ids | tail -1 >> gpurun_out/r/delaunay_stages.log
+mkdir -p gpurun_out/t
+for cfg in "16 16" "16 8" "8 8" "4 4"; do
+  set -- $cfg
+  echo "== waves $1 group $2" >> gpurun_out/t/coop_groups.log
+  RF_DELAUNAY_COOP_WAVES=$1 RF_DELAUNAY_COOP_GROUP=$2 RADFOAM_HIP_LIB=$R/radfoam_amd/libradfoam_hip_coopsec.so timeout 600 python scripts/gpu_delaunay_stages.py 2>&1 | grep -v amdgpu.ids | tail -3 >> gpurun_out/t/coop_groups.log
 done
-tail -4 gpurun_out/r/delaunay_stages.log
+cat gpurun_out/t/coop_groups.log

@@ -10,7 +10,7 @@ from radfoam_amd import foam
 n = 200000
 fm = foam.make_synthetic_foam(n, 0, 11, cache_dir=foam.default_cache_dir())
 pts = fm["points"]; tree = S.aabb_tree(pts); depth = S.pow2_round_up(n).bit_length() - 1
-L = S.lib(); L.star_host_trace.restype = C.c_int
+L = S.lib(); L.star_host_trace.restype = C.c_int; L.star_host_set_sweep(0)   # the kernels compile the sweep out
 first, count, cap = 64 * 1000, 64 * 200, 160
 out = np.zeros((count, cap), dtype=np.uint32); lens = np.zeros(count, dtype=np.uint32)
 L.star_host_trace(C.c_void_p(pts.ctypes.data), C.c_uint32(n), C.c_void_p(tree.ctypes.data), C.c_uint32(depth), C.c_uint32(12), C.c_uint32(512),
@@ -64,3 +64,23 @@ def persistent(K, SEED=400, chunk=1024):
 print("today (one star per lane, query-synchronous): %.0f node-steps per 64 stars" % lockstep.mean())
 for K in (1, 8, 16, 32):
     print("persistent waves, refill when >= %2d lanes are idle (400 node-steps per refill): %.0f" % (K, persistent(K)))
+
+# ---- a budget of tree nodes per STAR: a lane whose star has used it up stops, its star is redone in a second launch of the
+# same kernel over the list of such stars (waves of 64 stars that are all expensive: alike, so lockstep costs little there)
+def with_star_budget(cap):
+    cum = np.cumsum(nodes * mask, axis=1)
+    keep = mask & (cum - nodes * mask < cap)            # queries that start within the budget run (the last one to its end)
+    Wk = (nodes * keep).reshape(-1, 64, nodes.shape[1])
+    first = Wk.max(1).sum(1).mean()
+    over = np.where((nodes * mask).sum(1) > cap)[0]
+    again = 0.0
+    if over.size:
+        pad = (-over.size) % 64
+        idx = np.concatenate([over, over[:pad]]) if pad else over
+        again = (nodes[idx] * mask[idx]).reshape(-1, 64, nodes.shape[1]).max(1).sum(1).sum() / (count / 64.0)
+    return first, again, over.size / count
+
+
+for cap in (1500, 2000, 2500, 3000, 4000, 1 << 30):
+    f, a, frac = with_star_budget(cap)
+    print("star budget %10d nodes: first launch %.0f + second launch %.0f = %.0f node-steps per 64 stars (%.1f %% of the stars redone)" % (cap, f, a, f + a, 100 * frac))
