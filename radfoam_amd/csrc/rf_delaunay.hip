@@ -37,6 +37,18 @@
 #define RF_STAR_FN __device__ __forceinline__
 #define RF_STAR_NOINLINE __device__ __noinline__
 #define RF_STAR_NOUNROLL _Pragma("nounroll")
+#define RF_STAR_ANY(x) (__ballot(x) != 0ull)
+// the smallest value over the lanes of the wave, as a wave-uniform (scalar) value: rf_star.hpp, star_top_level.  A lane that
+// has left contributes whatever its register holds -- a smaller bound at worst, which costs tests and never misses one.
+static __device__ __forceinline__ uint32_t rf_wave_min(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
+        v = o < v ? o : v;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+#define RF_STAR_UNIFORM_MIN(x) rf_wave_min(x)
 #include "rf_star.hpp"
 
 namespace rf {

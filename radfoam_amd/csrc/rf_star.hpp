@@ -39,6 +39,9 @@
 #error "define RF_STAR_FN, RF_STAR_NOINLINE and RF_STAR_NOUNROLL before including rf_star.hpp"
 #endif
 
+#ifndef RF_STAR_ANY   // true while any lane of the wave says so (the kernels: a ballot); a star on its own: itself
+#define RF_STAR_ANY(x) (x)
+#endif
 #ifndef RF_STAR_TRACE_QUERY   // instrumentation hook of the host harness: (tree nodes of the query, found a point)
 #define RF_STAR_TRACE_QUERY(nodes, found) ((void)0)
 #endif
@@ -843,7 +846,7 @@ RF_STAR_FN bool search_subtree(S &s, const Tree &tr, const float *pts, int t, co
 #endif
 template <typename S>
 RF_STAR_FN uint32_t star_search(S &s, const Tree &tr, const float *pts, int t, const HullSet &hull,
-                                float *out_q, uint32_t &visited) {
+                                float *out_q, uint32_t &visited, uint32_t top_level = 1u) {
     Region R;
     R.f = s.t[t].f;
     R.ghost = (R.f & kGhost) != 0;
@@ -899,14 +902,16 @@ RF_STAR_FN uint32_t star_search(S &s, const Tree &tr, const float *pts, int t, c
     const uint32_t leaf_depth = tr.depth - kLeafBits;
     if (RF_STAR_BOTTOM_UP && R.ball && leaf_depth >= 1u && leaf_depth < 32u) {
         // phase 1: which ancestors' siblings does the ball reach?  (independent loads: addresses from s.self alone)
+        // (`top_level`: no ball of this star reaches the sibling of an ancestor above that level -- star_top_level)
         uint32_t reach = 0;
-        for (uint32_t d = leaf_depth; d >= 1u; --d) {
+        top_level = top_level < 1u ? 1u : top_level;   // (d >= 0 would never end)
+        for (uint32_t d = leaf_depth; d >= top_level; --d) {
             const uint32_t sib = (s.self >> (tr.depth - d)) ^ 1u;
             if ((sib << (tr.depth - d)) >= tr.n) continue;
             if (box_dist2(tree_node(tr, d, sib), R.cx, R.cy, R.cz) <= R.rp2) reach |= 1u << d;
         }
-        visited += leaf_depth;
-        spent += leaf_depth;
+        visited += leaf_depth + 1u - top_level;
+        spent += leaf_depth + 1u - top_level;
         // phase 2: p_i's own bucket, then the reached siblings from the nearest level up (one loop: see search_subtree)
         in_budget = search_subtree(s, tr, pts, t, R, leaf_depth, s.self >> kLeafBits, reach, best, best_id, out_q,
                                    visited, spent, budget);
@@ -1158,8 +1163,8 @@ RF_STAR_FN int sweep_collect(S &s, const Tree &tr, const float *pts, float r2, S
     const float px = s.p[0], py = s.p[1], pz = s.p[2];
     const uint32_t leaf_depth = tr.depth - kLeafBits;
     int count = 0;
-    bool duplicate = false;
-    while (!w.done && count + (1 << kLeafBits) <= cap) {
+    bool duplicate = false, over = false;
+    while (!w.done && !over && count + (1 << kLeafBits) <= cap) {
         const uint32_t depth = w.d0 + w.ld;
         const uint32_t idx = (w.k0 << w.ld) | (w.vidx ^ w.flip);
         const uint32_t first = idx << (tr.depth - depth);
@@ -1167,8 +1172,8 @@ RF_STAR_FN int sweep_collect(S &s, const Tree &tr, const float *pts, float r2, S
         if (first < tr.n) {
             const float *nd = tree_node(tr, depth, idx);
             ++visited;
-            if (++w.spent > budget) return -1;
-            if (box_dist2(nd, px, py, pz) <= r2) {
+            over = ++w.spent > budget;
+            if (!over && box_dist2(nd, px, py, pz) <= r2) {
                 if (depth < leaf_depth) {
                     descend = true;
                 } else {
@@ -1216,7 +1221,7 @@ RF_STAR_FN int sweep_collect(S &s, const Tree &tr, const float *pts, float r2, S
             const float *q = pts + 3 * (size_t)out[c];
             if (q[0] == px && q[1] == py && q[2] == pz) s.status = kDuplicate;
         }
-    return count;
+    return over ? -1 : count;
 }
 
 // is the ball of triangle t inside a swept reach of squared radius r2?
@@ -1228,63 +1233,96 @@ RF_STAR_FN bool swept_ball(const S &s, int t, float r2) {
 
 // Offers every point within reach of the star's (ordinary) balls to the link and certifies the triangles whose balls
 // that covers.  Returns the squared radius that was swept (0: nothing); triangles the star gets LATER are final too if
-// their ball lies inside it.  The star may fail on the way (s.status).
+// their ball lies inside it.  The star may fail on the way (s.status).  The rounds are the WAVE's (RF_STAR_ANY): all
+// lanes walk, then all lanes offer their lists.
 template <typename S>
 RF_STAR_FN float star_sweep(S &s, const Tree &tr, const float *pts, uint32_t budget, uint32_t &visited,
                             uint32_t &inserted) {
     float r2 = sweep_reach(s);
-    if (!(r2 > 0.0f) || tr.depth <= (uint32_t)kLeafBits) return 0.0f;
+    bool more = r2 > 0.0f && tr.depth > (uint32_t)kLeafBits;
+    bool swept = more;
     SweepWalk w;
-    sweep_begin(s, tr, r2, w, visited);
+    w.done = true;
+    if (more) sweep_begin(s, tr, r2, w, visited);
     uint32_t cand[kSweepCap];
     int offered = 0, rounds = 0;
-    while (!w.done) {
-        ++rounds;
-        const int n = sweep_collect(s, tr, pts, r2, w, cand, kSweepCap, budget, visited);
-        if (s.status != kOk) return 0.0f;
-        if (n < 0) {   // out of budget: what was inserted stands, nothing is certified here
-            RF_STAR_TRACE_SWEEP(3, offered, rounds, w.spent);
-            return 0.0f;
-        }
-#if defined(RF_STAR_EXPERIMENT_STAGE) && RF_STAR_EXPERIMENT_STAGE == 2   // timing only: seeds + the walk, candidates dropped
-        offered += n;
-        continue;
-#endif
-        // the link's vertices are in the list too: a 64-bit filter over a hash of the id, the slots only on a filter hit
-        // (a point this loop inserts is not a candidate again, so the filter need not follow the link within a round)
-        unsigned long long filter = 0ull;
-        int top = 1;
-        for (int k = 1; k < S::kV; ++k) {   // (no branch: see free_slot)
-            const bool used = s.v[k].use != 0;
-            filter |= (unsigned long long)used << vertex_hash(s.v[k].g);
-            top = used ? k + 1 : top;
-        }
-        for (int c = 0; c < n; ++c) {
-            const uint32_t k = cand[c];
-            if ((filter >> vertex_hash(k)) & 1ull) {
-                bool vertex = false;
-                for (int v = 1; v < top; ++v) vertex |= (s.v[v].use != 0) & (s.v[v].g == k);
-                if (vertex) continue;
+    while (RF_STAR_ANY(more)) {
+        if (more) {
+            ++rounds;
+            const int n = sweep_collect(s, tr, pts, r2, w, cand, kSweepCap, budget, visited);
+            if (s.status != kOk || n < 0) {   // failed / out of budget: what was inserted stands, nothing is certified here
+                more = swept = false;
+            } else {
+                // the link's vertices are in the list too: a 64-bit filter over a hash of the id, the slots only on a
+                // filter hit (a point this loop inserts is not a candidate again: the filter need not follow the link)
+                unsigned long long filter = 0ull;
+                int top = 1;
+                for (int k = 1; k < S::kV; ++k) {   // (no branch: see free_slot)
+                    const bool used = s.v[k].use != 0;
+                    filter |= (unsigned long long)used << vertex_hash(s.v[k].g);
+                    top = used ? k + 1 : top;
+                }
+                bool failed = false;
+                for (int c = 0; c < n; ++c) {
+                    const uint32_t k = cand[c];
+                    bool vertex = failed;
+                    if ((filter >> vertex_hash(k)) & 1ull)
+                        for (int v = 1; v < top; ++v) vertex |= (s.v[v].use != 0) & (s.v[v].g == k);
+                    if (!vertex) {
+                        const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
+                        const int r = star_insert(s, k, q);
+                        failed = r < 0;   // overflow / broken: s.status says which
+                        inserted += r > 0;
+                    }
+                }
+                offered += n;
+                if (failed) more = swept = false;
+                else if (w.done) more = false;
+                // the balls the star has now need less: the rest of the walk is shorter (never longer: what the walk
+                // passed was measured against the reach of that time)
+                else r2 = fminf(r2, sweep_reach(s));
             }
-            const float q[3] = {pts[3 * (size_t)k], pts[3 * (size_t)k + 1], pts[3 * (size_t)k + 2]};
-            const int r = star_insert(s, k, q);
-            if (r < 0) return 0.0f;   // overflow / broken: s.status says which
-            inserted += r > 0;
         }
-        offered += n;
-        // the balls the star has now need less: the rest of the walk is shorter (never longer: what the walk passed
-        // was measured against the reach of that time)
-        if (!w.done) r2 = fminf(r2, sweep_reach(s));
     }
-    RF_STAR_TRACE_SWEEP(0, offered, rounds, w.spent);
-#if defined(RF_STAR_EXPERIMENT_STAGE) && RF_STAR_EXPERIMENT_STAGE == 2
-    for (int t = 0; t < s.nt; ++t) s.t[t].f |= kCertified;
-    return r2;
-#endif
+    RF_STAR_TRACE_SWEEP(swept ? 0 : 3, offered, rounds, w.spent);
+    if (!swept || s.status != kOk) return 0.0f;
     // every point within sqrt(r2) of p_i has been offered: a ball inside that reach is empty
     for (int t = 0; t < s.nt; ++t)
         if (swept_ball(s, t, r2)) s.t[t].f |= kCertified;
     return r2;
+}
+
+// The highest level of the tree (smallest d >= 1) at which the sibling of p_i's ancestor lies within reach of ANY ball the
+// star has or will have; 1 when the star has a ghost or a flat triangle, whose regions no ball around p_i bounds.  A ball
+// passes through p_i, so it lies within 2 r of it, and the region the balls cover only shrinks as points go in (see the
+// sweep above): what the ball of radius 2 max r around p_i does not reach now, no later query of this star has to test.
+// A query of the bottom-up search tests the sibling of every ancestor against its own ball first -- 19 boxes for 2 M
+// points, 27 queries a star: a third of the nodes the first pass visits; with this bound it tests the levels near the
+// leaves that the star's neighbourhood spans.  In the kernels the bound is made the WAVE's (the lowest of its 64 stars,
+// consecutive points of the kd-order: RF_STAR_UNIFORM_MIN, defined by the includer): the loop over the levels stays a loop
+// of the wave with a scalar trip count.
+#ifndef RF_STAR_UNIFORM_MIN
+#define RF_STAR_UNIFORM_MIN(x) (x)
+#endif
+#ifndef RF_STAR_TOP_LEVEL
+#define RF_STAR_TOP_LEVEL 1
+#endif
+template <typename S>
+RF_STAR_FN uint32_t star_top_level(const S &s, const Tree &tr, uint32_t &visited) {
+    if (s.v[0].use != 0 || tr.depth <= (uint32_t)kLeafBits) return 1u;
+    float hi = 0.0f;
+    for (int t = 0; t < s.nt; ++t) hi = fmaxf(hi, s.t[t].sr);
+    if (!(hi < 1.0e37f)) return 1u;
+    const float r2 = 4.0f * hi * 1.0001f + 1e-37f;
+    const uint32_t leaf_depth = tr.depth - kLeafBits;
+    uint32_t top = leaf_depth + 1u;
+    for (uint32_t d = leaf_depth; d >= 1u; --d) {
+        const uint32_t sib = (s.self >> (tr.depth - d)) ^ 1u;
+        if ((sib << (tr.depth - d)) >= tr.n) continue;
+        if (box_dist2(tree_node(tr, d, sib), s.p[0], s.p[1], s.p[2]) <= r2) top = d;
+    }
+    visited += leaf_depth;
+    return top;
 }
 
 // Build the star from `nseeds` candidate points, then certify every triangle.
@@ -1303,35 +1341,51 @@ RF_STAR_FN void star_build(S &s, const Tree &tr, const float *pts, const HullSet
         if (s.status != kOk) return;
     }
 #endif
-    for (;;) {
-        int t = -1;
-        for (int k = 0; k < s.nt; ++k)
-            if (!(s.t[k].f & kCertified)) {
-                t = k;
-                break;
-            }
-        if (t < 0) break;
-#if RF_STAR_SWEEP
-        // a triangle that came with an insertion after the sweep: final if its ball lies inside what was swept
-        if (swept > 0.0f && swept_ball(s, t, swept)) {
-            s.t[t].f |= kCertified;
-            continue;
-        }
+    // The loop is the WAVE's: every lane whose star is still open takes one of its open triangles per trip, and the lanes
+    // meet again at the end of the trip (RF_STAR_ANY: true while any lane of the wave says so; defined by the includer,
+    // on the host a star is on its own).  Written with a `return` / `break` per lane instead, where the lanes of a wave
+    // meet again is the compiler's choice, and it changed with unrelated edits: the same star code ran the first pass in
+    // 163 or in 311 ms (profiles/r06/r_delaunay_stages_ab.log).
+#if RF_STAR_TOP_LEVEL
+    const uint32_t top_level = RF_STAR_UNIFORM_MIN(star_top_level(s, tr, visited));
+#else
+    const uint32_t top_level = 1u;
 #endif
-        float q[3];
-        const uint32_t before = visited;
-        const uint32_t j = star_search(s, tr, pts, t, hull, q, visited);
-        RF_STAR_TRACE_QUERY(visited - before, j != kInfinity);
-        if (s.status != kOk) return;
-        if (j == kInfinity) {
-            s.t[t].f |= kCertified;
-            continue;
+    bool open = true;
+    while (RF_STAR_ANY(open)) {
+        if (open) {
+            int t = -1;
+            for (int k = 0; k < s.nt; ++k)
+                if (!(s.t[k].f & kCertified)) {
+                    t = k;
+                    break;
+                }
+            if (t < 0) {
+                open = false;
+            }
+#if RF_STAR_SWEEP
+            // a triangle that came with an insertion after the sweep: final if its ball lies inside what was swept
+            else if (swept > 0.0f && swept_ball(s, t, swept)) {
+                s.t[t].f |= kCertified;
+            }
+#endif
+            else {
+                float q[3];
+                const uint32_t before = visited;
+                const uint32_t j = star_search(s, tr, pts, t, hull, q, visited, top_level);
+                RF_STAR_TRACE_QUERY(visited - before, j != kInfinity);
+                if (s.status != kOk) {
+                    open = false;
+                } else if (j == kInfinity) {
+                    s.t[t].f |= kCertified;
+                } else if (star_insert(s, j, q) <= 0) {
+                    if (s.status == kOk) s.status = kBroken;   // the search said "conflict", the insertion must agree
+                    open = false;
+                } else {
+                    ++inserted;
+                }
+            }
         }
-        if (star_insert(s, j, q) <= 0) {
-            if (s.status == kOk) s.status = kBroken;   // the search said "conflict", the insertion must agree
-            return;
-        }
-        ++inserted;
     }
 }
 
