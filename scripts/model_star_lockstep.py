@@ -84,3 +84,22 @@ def with_star_budget(cap):
 for cap in (1500, 2000, 2500, 3000, 4000, 1 << 30):
     f, a, frac = with_star_budget(cap)
     print("star budget %10d nodes: first launch %.0f + second launch %.0f = %.0f node-steps per 64 stars (%.1f %% of the stars redone)" % (cap, f, a, f + a, 100 * frac))
+
+# ---- lanes grouped by cost: within chunks of `chunk` consecutive stars (a compact region of the kd-order: what a block's
+# waves share of the tree stays shared) the stars are dealt to the waves in the order of a cost proxy known before the
+# build -- the number of queries (about twice the previous neighbour count on an incremental rebuild)
+def grouped(chunk, key):
+    total = 0.0
+    for c0 in range(0, count - chunk + 1, chunk):
+        idx = np.arange(c0, c0 + chunk)
+        idx = idx[np.argsort(key[idx], kind="stable")]
+        Wk = (nodes[idx] * mask[idx]).reshape(-1, 64, nodes.shape[1])
+        total += Wk.max(1).sum(1).sum()
+    return total / ((count // chunk) * chunk / 64.0)
+
+
+nq = mask.sum(1)
+tot = (nodes * mask).sum(1)
+for chunk in (256, 1024, 4096):
+    print("chunks of %4d stars, waves dealt by the number of queries: %.0f node-steps per 64 stars; by the star's total nodes (an oracle): %.0f (now %.0f)" %
+          (chunk, grouped(chunk, nq), grouped(chunk, tot), lockstep.mean()))

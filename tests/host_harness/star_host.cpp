@@ -31,7 +31,7 @@ static thread_local uint32_t *g_sweep_rec = nullptr;   // star_host_sweep_trace:
         }                                                                      \
     } while (0)
 #define RF_STAR_SWEEP 1   // compiled in here whatever the kernels' default is: the tests run it both ways
-static int g_star_sweep = 1;   // star_host_set_sweep: the sweep of rf_star.hpp on / off (tests compare both ways)
+static int g_star_sweep = 0;   // star_host_set_sweep: the sweep of rf_star.hpp on / off (off: what the kernels ship; tests run both)
 #define RF_STAR_SWEEP_ON g_star_sweep
 #define RF_STAR_FN static inline
 #define RF_STAR_NOINLINE static __attribute__((noinline))

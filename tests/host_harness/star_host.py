@@ -70,7 +70,7 @@ def aabb_tree(points: np.ndarray) -> np.ndarray:
 
 
 def delaunay(points: np.ndarray, knn: int = 12, old=None, stride: int = 250, ghost_budget: int = 512,
-             sweep: bool = True):
+             sweep: bool = False):
     """(offsets, adjacency, info) through the host build of the star code; sweep=False: every triangle certified by a
     query of its own (rf_star.hpp: star_sweep compiled in but switched off)."""
     lib().star_host_set_sweep(1 if sweep else 0)

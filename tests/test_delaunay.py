@@ -70,8 +70,12 @@ def test_predicates_against_rationals():
     assert zeros > 100   # the degenerate cases were really exercised
 
 
+@pytest.mark.parametrize("sweep", [False, True], ids=["queries", "sweep"])
 @pytest.mark.parametrize("name", ["uniform", "clustered", "sheet", "offset"])
-def test_host_stars_equal_qhull(name):
+def test_host_stars_equal_qhull(name, sweep):
+    """Both ways of certifying a star: a tree walk per triangle (what the kernels ship: RF_STAR_SWEEP=0) and the sweep --
+    one range query per star that offers every point within reach of its balls to the link (rf_star.hpp: star_sweep;
+    built, equal to Qhull, measured out on the GPU and compiled out there)."""
     rng = np.random.default_rng(3)
     if name == "uniform":
         pts = rng.uniform(-1, 1, size=(12000, 3))
@@ -84,9 +88,26 @@ def test_host_stars_equal_qhull(name):
         pts = rng.uniform(-1, 1, size=(5000, 3)) + 1000.0
     pts = _kd(pts)
     off0, adj0 = foam.delaunay_csr(pts)
-    off, adj, info = S.delaunay(pts)
+    off, adj, info = S.delaunay(pts, sweep=sweep)
     assert info["bad"] == 0
     assert np.array_equal(off, off0) and np.array_equal(adj, adj0)
+
+
+def test_host_sweep_certifies_with_a_fraction_of_the_tree_walks():
+    """The sweep's point: the same lists from a fifth of the tree nodes (on the GPU the nodes are not what bounds the
+    launch -- DESIGN.md section 4.6 -- which is why it is compiled out there)."""
+    rng = np.random.default_rng(12)
+    pts = _kd(rng.uniform(-1, 1, size=(20000, 3)))
+    off0, adj0 = foam.delaunay_csr(pts)
+    moved = (pts + rng.normal(0, 0.03 * (8.0 / 20000) ** (1 / 3), size=pts.shape)).astype(np.float32)
+    off1, adj1 = foam.delaunay_csr(moved)
+    nodes = {}
+    for sweep in (False, True):
+        off, adj, info = S.delaunay(moved, old=(off0, adj0), sweep=sweep)
+        assert info["bad"] == 0
+        assert np.array_equal(off, off1) and np.array_equal(adj, adj1)
+        nodes[sweep] = info["visited"].mean()
+    assert nodes[True] < 0.4 * nodes[False]
 
 
 @pytest.mark.parametrize("n", [33, 63, 65, 641, 642, 643, 1025, 2050])
@@ -159,9 +180,10 @@ def test_host_incremental_seeds_give_the_same_lists():
     off, adj, _ = S.delaunay(pts)
     moved = (pts + rng.normal(0, 2e-3, size=pts.shape)).astype(np.float32)   # ~ 5 % of the point spacing
     off0, adj0 = foam.delaunay_csr(moved)
-    off1, adj1, info = S.delaunay(moved, old=(off, adj))
-    assert info["bad"] == 0
-    assert np.array_equal(off1, off0) and np.array_equal(adj1, adj0)
+    for sweep in (False, True):
+        off1, adj1, info = S.delaunay(moved, old=(off, adj), sweep=sweep)
+        assert info["bad"] == 0
+        assert np.array_equal(off1, off0) and np.array_equal(adj1, adj0)
     assert not np.array_equal(adj, adj0)   # the move did change the triangulation
 
 
