@@ -1,10 +1,11 @@
 # the batch of one gpurun call (rewritten per call; what each call ran is recorded in profiles/README.md)
-# this call (r06 ac): the training loop over 1000 iterations on the final sources (round 5: 33.2 it/s)
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/ac
-(timeout 1500 python bench.py --workload train-loop --steps 1000 2>gpurun_out/ac/loop.err | tail -1) > gpurun_out/ac/train-loop_1000.json
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/ac/train-loop_1000.json")); det=d["detail"]
-print(d["value"], d["unit"], {k:v for k,v in det["ms_per_iteration"].items() if v>0.3}, det.get("loss_first"), det.get("loss_last"), det.get("rebuilds"))
-PY
+# this call (r06 ae): the walk's child order from the parent's box (no load of the left child's bound before descending) against the committed walk (head)
+R=$GRAFT_REPO_ROOT
+cd $R
+mkdir -p gpurun_out/ae
+for v in base head base head; do
+  L=$R/radfoam_amd/libradfoam_hip_$v.so
+  [ "$v" = "base" ] && L=$R/radfoam_amd/libradfoam_hip.so
+  RADFOAM_HIP_LIB=$L timeout 300 python scripts/gpu_delaunay_stages.py 2>&1 | grep -v amdgpu.ids | tail -1 >> gpurun_out/ae/child_order_ab.log
+done
+cat gpurun_out/ae/child_order_ab.log
