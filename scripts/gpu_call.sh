@@ -1,4 +1,4 @@
 # the batch of one gpurun call (rewritten per call; what each call ran is recorded in profiles/README.md)
-# this call (r06 af): rocprofv3 kernel trace + the four PMC passes of the triangulation's kernels on the final sources
+# this call (r06 ag): the new GPU test of the second pass's other instantiations, and the triangulation's GPU tests
 cd $GRAFT_REPO_ROOT
-SKIP_TESTS=1 PMC=1 DELAUNAY_ARGS="2000000 5" bash scripts/gpu_delaunay.sh 2>&1 | grep -v "^\[gpurun\]\|^W2026\|^E2026\|^I2026" | tail -30 | tee gpurun_out/delaunay_profile.log
+timeout 1200 python -m pytest tests/test_delaunay.py -m gpu -q -x 2>&1 | tail -4

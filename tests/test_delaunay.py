@@ -357,6 +357,30 @@ def test_gpu_hub_and_shell():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("waves,group", [(4, 1), (4, 4), (8, 4), (16, 16)])
+def test_gpu_second_pass_configurations(waves, group):
+    """The second pass's other instantiations (waves per rim star x waves per query; the default is 8 x 8): same lists.
+    The knobs are read once per process, so each configuration gets a process of its own."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests.test_delaunay import _shell_cloud, _t\n"
+        "from radfoam_amd import foam, triangulation\n"
+        "pts = _shell_cloud(np.random.default_rng(2), 6000)\n"
+        "off0, adj0 = foam.delaunay_csr(pts)\n"
+        "adj, off, stats = triangulation.delaunay_adjacency(_t(pts))\n"
+        "assert stats['large_stars'] > 100\n"
+        "assert np.array_equal(off.cpu().numpy(), off0) and np.array_equal(adj.cpu().numpy(), adj0)\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, RF_DELAUNAY_COOP_WAVES=str(waves), RF_DELAUNAY_COOP_GROUP=str(group))
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_gpu_stars_on_the_cached_foams():
     """Whole BASELINE foams: the lists equal the cached Qhull CSR (500 k always; 2 M when its cache is here)."""
     import os
